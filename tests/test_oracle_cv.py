@@ -1,0 +1,211 @@
+"""Known-answer tests for the oracle's restatement of the OpenCV primitives (oracle/cvref.c).
+
+PARITY UNPINNED: OpenCV is not installed and the reference holds no cv2 output,
+so these stages are held by hand-derived answers only.
+"""
+import numpy as np
+import pytest
+
+from oracle import uwie_oracle as orc
+
+
+def test_rgb2gray_kats():
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0]]], np.uint8)
+    for shift in (14, 15):
+        assert orc.cv_rgb2gray_u8(px, shift).tolist() == [[76, 150, 29, 255, 0]]
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (31, 17, 3), dtype=np.uint8).astype(np.int64)
+    want = (rgb[..., 0] * 9798 + rgb[..., 1] * 19235 + rgb[..., 2] * 3735 + 16384) >> 15
+    assert np.array_equal(orc.cv_rgb2gray_u8(rgb.astype(np.uint8), 15), want.astype(np.uint8))
+
+
+def test_rgb2lab_kats():
+    # CIE L*a*b* of the sRGB primaries (D65), scaled L*255/100, a+128, b+128, rounded
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    want = [[255, 128, 128], [0, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20]]
+    assert orc.cv_rgb2lab_u8(px)[0].tolist() == want
+
+
+def test_lab_roundtrip_grays_exact_and_colours_close():
+    g = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    back = orc.cv_lab2rgb_u8(orc.cv_rgb2lab_u8(g))
+    assert np.abs(back.astype(int) - g.astype(int)).max() <= 1
+    lab = orc.cv_rgb2lab_u8(g)
+    assert np.all(lab[..., 1] == 128) and np.all(lab[..., 2] == 128)
+    assert np.all(np.diff(lab[0, :, 0].astype(int)) >= 0)
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(40, 216, (64, 64, 3), dtype=np.uint8)
+    err = np.abs(orc.cv_lab2rgb_u8(orc.cv_rgb2lab_u8(rgb)).astype(int) - rgb.astype(int))
+    assert err.mean() < 1.0 and err.max() <= 6
+
+
+def test_lab_against_float_cie_formula():
+    """The fixed-point path tracks the floating CIE formulas (11-bit gamma table: <2 codes worst case)."""
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, (4096, 1, 3), dtype=np.uint8)
+    c = rgb.reshape(-1, 3) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ M.T / np.array([0.950456, 1.0, 1.088754])
+    f = np.where(xyz > 216 / 24389, np.cbrt(xyz), 841 / 108 * xyz + 16 / 116)
+    L = np.where(xyz[:, 1] > 216 / 24389, 116 * np.cbrt(xyz[:, 1]) - 16, 903.3 * xyz[:, 1])
+    want = np.stack([L * 255 / 100, 500 * (f[:, 0] - f[:, 1]) + 128, 200 * (f[:, 1] - f[:, 2]) + 128], 1)
+    got = orc.cv_rgb2lab_u8(rgb).reshape(-1, 3).astype(float)
+    err = np.abs(got - np.clip(want, 0, 255))
+    assert err.max() < 2.0 and err.mean() < 0.35
+
+
+@pytest.mark.parametrize("k", [15, 20, 10, 3, 1])
+def test_box_filter_constant_and_ramp(k):
+    H, W = 40, 64
+    const = np.full((H, W), 0.375)
+    assert np.allclose(orc.cv_box_filter_f64(const, k), 0.375, rtol=0, atol=1e-15)
+    s = 0.25
+    ramp = np.tile(s * np.arange(W, dtype=np.float64), (H, 1))
+    out = orc.cv_box_filter_f64(ramp, k)
+    a = k // 2
+    # window = [x - a, x - a + k - 1]; its mean on a ramp is v(x) + s*((k-1)/2 - a)
+    xs = np.arange(a, W - (k - 1 - a))
+    assert np.allclose(out[:, xs], ramp[:, xs] + s * ((k - 1) / 2 - a), rtol=0, atol=1e-12)
+    vr = orc.cv_box_filter_f64(ramp.T.copy(), k)
+    assert np.allclose(vr[xs, :], ramp.T[xs, :] + s * ((k - 1) / 2 - a), rtol=0, atol=1e-12)
+
+
+def test_box_filter_matches_direct_reflect101_window_mean():
+    rng = np.random.default_rng(3)
+    for (H, W, k) in [(9, 13, 15), (23, 17, 20), (5, 7, 10), (30, 41, 15)]:
+        src = rng.random((H, W))
+        a = k // 2
+        idx_y = [orc_reflect(y, H) for y in range(-a, H - a + k - 1)]
+        idx_x = [orc_reflect(x, W) for x in range(-a, W - a + k - 1)]
+        ext = src[np.ix_(idx_y, idx_x)]
+        want = np.array([[ext[y:y + k, x:x + k].sum() for x in range(W)] for y in range(H)]) / (k * k)
+        assert np.allclose(orc.cv_box_filter_f64(src, k), want, rtol=0, atol=1e-13)
+
+
+def orc_reflect(p, n):
+    if n == 1:
+        return 0
+    while p < 0 or p >= n:
+        p = -p if p < 0 else 2 * (n - 1) - p
+    return p
+
+
+def test_guided_filter_closed_forms():
+    H, W = 32, 48
+    I = np.full((H, W), 0.5)
+    p = np.full((H, W), 0.25)
+    # constant guide: var = cov = 0 -> a = 0, b = mean_p -> q = p
+    assert np.allclose(orc.guided_filter(I, p, 15, 0.5), 0.25, atol=1e-14)
+    # p == I with eps -> 0 reproduces I (a -> 1, b -> 0) wherever var_I > 0
+    rng = np.random.default_rng(4)
+    I = rng.random((H, W))
+    q = orc.guided_filter(I, I, 15, 1e-12)
+    assert np.abs(q - I).max() < 0.6  # q = mean_a*I + mean_b, a ~ 1
+    # huge eps: a -> 0, q -> box(box(p))
+    q = orc.guided_filter(I, p, 15, 1e12)
+    assert np.allclose(q, 0.25, atol=1e-9)
+
+
+def test_clahe_constant_image_closed_form():
+    # all mass in one bin v: clipped to clip, excess spread evenly -> lut[i] known in closed form
+    H, W, v, c = 64, 128, 100, 2.0
+    img = np.full((H, W), v, np.uint8)
+    tile = (W // 8) * (H // 8)
+    clip = max(int(c * tile / 256), 1)
+    excess = tile - clip
+    hist = np.zeros(256, np.int64)
+    hist[v] = clip
+    hist += excess // 256
+    res = excess % 256
+    if res:
+        step = max(256 // res, 1)
+        i = 0
+        while i < 256 and res > 0:
+            hist[i] += 1
+            i += step
+            res -= 1
+    lut = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * np.float32(255.0 / tile)), 0, 255)
+    out = orc.cv_clahe_u8(img, c, (8, 8))
+    assert np.all(out == int(lut[v]))
+
+
+def test_clahe_pads_ragged_sizes_and_keeps_shape():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    out = orc.cv_clahe_u8(img, 2.0, (8, 8))
+    assert out.shape == img.shape and out.dtype == np.uint8
+    # a huge clip limit turns CLAHE into plain tile-wise equalisation: output stays monotone in input per tile centre
+    flat = np.full((64, 64), 7, np.uint8)
+    assert np.all(orc.cv_clahe_u8(flat, 1e9, (8, 8)) == 255)
+
+
+def test_equalize_hist_two_level_and_constant():
+    img = np.zeros((10, 10), np.uint8)
+    img[:, 5:] = 200
+    out = orc.cv_equalize_hist_u8(img)
+    assert out[0, 0] == 0 and out[0, 9] == 255
+    assert np.all(orc.cv_equalize_hist_u8(np.full((4, 4), 9, np.uint8)) == 9)
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    hist = np.bincount(img.ravel(), minlength=256)
+    i0 = np.flatnonzero(hist)[0]
+    scale = np.float32(255.0) / np.float32(img.size - hist[i0])
+    cs = np.cumsum(hist) - hist[i0]
+    lut = np.clip(np.rint(cs.astype(np.float32) * scale), 0, 255).astype(np.uint8)
+    lut[i0] = 0
+    assert np.array_equal(orc.cv_equalize_hist_u8(img), lut[img])
+
+
+def test_canny_step_edge_and_flat():
+    assert not orc.cv_canny_u8(np.full((20, 20), 128, np.uint8), 50, 150).any()
+    img = np.zeros((20, 30), np.uint8)
+    img[:, 15:] = 255
+    e = orc.cv_canny_u8(img, 50, 150)
+    # vertical step: Sobel responds at columns 14 and 15 with equal magnitude 4*255;
+    # NMS keeps m > left and m >= right -> exactly column 14 survives, on every row
+    assert np.all(e[:, 14] == 255) and e.sum() == 255 * 20
+    e = orc.cv_canny_u8(img.T.copy(), 50, 150)
+    assert np.all(e[14, :] == 255) and e.sum() == 255 * 20
+
+
+def test_canny_hysteresis_links_weak_to_strong():
+    # a ramp edge whose contrast decays along the row direction: strong at the top, weak at the bottom
+    img = np.zeros((40, 20), np.uint8)
+    for y in range(40):
+        img[y, 10:] = max(60 - y, 0) + 10  # Sobel magnitude 4*(70 - y) .. crosses 150 and 50
+    img[:, :10] = 10
+    e = orc.cv_canny_u8(img, 50, 150)
+    # the brighter side also carries the vertical ramp, so its column (10) wins the NMS; rows >= 33 are
+    # weak-only (4*step <= 150) and survive solely because hysteresis links them to the strong rows above
+    assert (e[:, 10] > 0).all() and e.sum() == 255 * 40
+    weak_only = np.zeros((40, 20), np.uint8)
+    weak_only[:, :10] = 10
+    weak_only[:, 10:] = 30  # magnitude 80: weak everywhere, no strong seed
+    assert not orc.cv_canny_u8(weak_only, 50, 150).any()
+
+
+def test_quadtree_descends_into_bright_low_red_flat_quadrant():
+    rng = np.random.default_rng(7)
+    img = (rng.random((64, 64, 3)) * 0.2).astype(np.float32)
+    img[32:, :32, :] = np.array([0.1, 0.9, 0.95], np.float32)  # bottom-left: bright, low red, no variance/edges
+    img[40, 7, :] = np.array([0.2, 1.0, 1.0], np.float32)
+    trace = []
+    A = orc.atmospheric_light(img, 1, trace=trace)
+    assert trace[0][4].index(max(trace[0][4])) == 2
+    assert A.dtype == np.float32 and A.shape == (3,)
+    assert A[1] >= 0.9 and A[0] <= 0.2
+
+
+def test_full_strategies_run_and_stay_in_range():
+    rng = np.random.default_rng(8)
+    u8 = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    for s in range(1, 7):
+        out = orc.enhance_u8(u8, s)
+        assert out.shape == u8.shape and out.dtype == np.uint8
+    x = orc.normalise_u8(u8)
+    for name, params in orc.CONFIG_STRATEGIES.items():
+        y = orc.DictStrategyOracle.apply_strategy(x, name, params)
+        assert y.shape == x.shape and y.min() >= 0 and y.max() <= 1
+    with pytest.raises(ValueError):
+        orc.DictStrategyOracle.apply_strategy(x, "nope", {})
