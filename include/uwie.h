@@ -1,0 +1,170 @@
+/*
+ * uwie.h -- C ABI of libuwie.so: the MI355X (gfx950) implementation of the
+ * underwater-image-enhancement hot path.
+ *
+ * The reference (submarine0418/underwater_image_enhancement) is pure Python and
+ * has NO FFI/plugin interface for this path; the entry points below are what a
+ * ctypes binding for it would call.  Each one names the reference interface it
+ * replaces (S6 = six_stadigy.py, ES = enhancement_strategies.py).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM); images are HWC,
+ *     RGB-interleaved, contiguous, batch-major: [batch][H][W][3];
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns without synchronising; scalars that the reference reads back on
+ *     the host (cast kind, atmospheric light, percentiles) stay on the device;
+ *   - the library never allocates or frees caller memory: scratch comes from
+ *     the caller (`d_workspace`, sized by uwie_workspace_bytes);
+ *   - return value: 0 on success, a negative UWIE_E_* code on failure; the
+ *     message is available from uwie_last_error() (thread-local);
+ *   - a context belongs to one device and one host thread/stream at a time.
+ */
+#ifndef UWIE_H_
+#define UWIE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWIE_OK 0
+#define UWIE_E_INVALID (-1)   /* bad argument (null pointer, size, unknown strategy: ES:500-501 ValueError) */
+#define UWIE_E_WORKSPACE (-2) /* workspace too small */
+#define UWIE_E_HIP (-3)       /* a HIP runtime call failed */
+#define UWIE_E_NODEVICE (-4)  /* no gfx950 device / code object cannot load */
+
+/* which reference surface's arithmetic to follow */
+#define UWIE_SURFACE_SIX 0  /* six_stadigy.EnhancementStrategies.strategy1..6 (S6:230-285)        */
+#define UWIE_SURFACE_DICT 1 /* enhancement_strategies.EnhancementStrategies.apply_strategy (ES:477) */
+
+/* strategy ids.  SIX: 1..6 as in S6:230-285.  DICT: the keys of ES:489-498. */
+#define UWIE_DICT_STRONG_DEHAZING 0
+#define UWIE_DICT_MEDIUM_DEHAZING 1
+#define UWIE_DICT_LIGHT_ENHANCEMENT 2
+#define UWIE_DICT_CLAHE_ENHANCEMENT 3
+#define UWIE_DICT_HISTOGRAM_EQUALIZATION 4
+
+#define UWIE_CAST_NORMAL 0
+#define UWIE_CAST_GREENISH 1
+#define UWIE_CAST_BLUISH 2
+
+typedef struct uwie_ctx uwie_ctx;
+
+/* Numeric parameters of one strategy.  uwie_params_init fills the reference's
+ * hard-coded (SIX, S6:230-285) or in-code default (DICT, ES:356-372,382-395,
+ * 405-419,428-441,466-473) values; the host wrapper overrides fields from the
+ * caller's params dict (config.py:28-75 value sets). */
+typedef struct uwie_params {
+    int32_t surface;       /* UWIE_SURFACE_*                                                     */
+    int32_t strategy;      /* see above                                                          */
+    int32_t cast_correct;  /* 1: detect_image_type + color_correction first (S6:409,413)         */
+    int32_t forced_cast;   /* -1: detect (if cast_correct).  UWIE_CAST_*: skip detection and apply
+                              color_correction for this kind (caller ran detect_image_type itself)  */
+    int32_t gray_shift;    /* RGB2GRAY fixed point: 15 (OpenCV 4.x, default) or 14               */
+    int32_t min_size;      /* quadtree leaf size (S6:49, ES:77): 1                               */
+    float omega;           /* S6:173 / ES:225                                                    */
+    int32_t gf_ksize;      /* guided-filter box WIDTH `r` (S6:31, ES:31)                         */
+    double gf_eps;         /* S6: 0.5/0.5/0.1 (:234,245,255); ES: always 0.001 (:209)            */
+    double L_low, L_high;  /* percentile stretch bounds in percent (S6:191, ES:252)              */
+    double wb_percentile;  /* S6:211 white_balance percentile; < 0 = stage absent                */
+    double clip_limit;     /* CLAHE clip limit (S6:202, ES:288); <= 0 = stage absent             */
+    int32_t tiles_x, tiles_y; /* CLAHE tile grid (S6: 8x8 fixed; ES: tile_grid_size)             */
+    double gamma;          /* S6:222 exponent g (x**g); ES:276 g (clip(x**(1/g)))                */
+    int32_t apply_gamma;   /* 0/1 (ES `apply_gamma`; S6 strategies 1,4,5,6 always 1)             */
+} uwie_params;
+
+const char *uwie_last_error(void);
+const char *uwie_version(void);
+
+int uwie_create(int device, uwie_ctx **out_ctx);
+void uwie_destroy(uwie_ctx *ctx);
+
+/* Fill `p` with the reference defaults for (surface, strategy). */
+int uwie_params_init(uwie_params *p, int surface, int strategy);
+
+/* Scratch bytes needed by uwie_enhance_u8 / any stage entry point for this shape. */
+size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p);
+
+/*
+ * enhance(u8 RGB) -> u8 RGB for a whole batch.
+ *   SIX : x = u8/255 (S6:406) -> [detect_image_type, color_correction (S6:409,413)]
+ *         -> strategyN (S6:230-285) -> (y*255).astype(uint8) (S6:430)
+ *   DICT: x = u8/255 (main.py:108) -> apply_strategy body (ES:350-474) -> (y*255).astype(uint8) (main.py:155)
+ * d_out_f32 (optional, may be NULL) receives the float image the reference's
+ * strategy function returns ([batch][H][W][3] float32; float64 values of the
+ * DICT surface are rounded to float32).
+ */
+int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float *d_out_f32, int batch, int H, int W,
+                    const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------- per-stage entry points (parity tests, composition) ---------------- */
+
+/* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */
+int uwie_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int W, int32_t *d_kind,
+                       float *d_mean_rgb, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* color_correction (S6:305-323) on x = u8/255: float32 [batch][H][W][3].  d_kind NULL = "normal". */
+int uwie_normalise_correct(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, float *d_out_f32, int batch,
+                           int H, int W, void *stream);
+
+/* estimate_atmospheric_light (S6:49-113, ES:77-144): greedy quadtree descent, A = brightest pixel of
+ * the leaf.  d_kind NULL = no cast correction.  d_trace (optional) receives per level, per image:
+ * {y0,x0,rows,cols} as int32[4] followed by the four float64 scores, i.e. 4 int32 + 4 double = 48 bytes,
+ * for at most 32 levels: [batch][32][48 bytes]. */
+int uwie_atmospheric_light(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, int batch, int H, int W,
+                           const uwie_params *p, float *d_A, void *d_trace, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* first half of estimate_transmission (S6:170-177 / ES:221-228): t0 = 1 - omega*min_c(x/(A+eps)) [clipped
+ * on the SIX surface] as float32 [batch][H][W], and the 8-bit gray guide [batch][H][W]. */
+int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, int batch,
+                           int H, int W, const uwie_params *p, float *d_t0, uint8_t *d_gray, void *stream);
+
+/* cv2.boxFilter(src, CV_64F, (k,k)) on float64 planes [batch][H][W] (S6:31-43). */
+int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int batch, int H, int W, int ksize,
+                        void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* guided_filter(gray/255, t0, r, eps) followed by clip(.,0.1,1) (S6:178-180, ES:229-232): float64 [batch][H][W]. */
+int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
+                       double eps, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* restore_image (S6:183-188): float32 [batch][H][W][3]. */
+int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t,
+                 int batch, int H, int W, float *d_out_f32, void *stream);
+
+/* np.percentile(img[:,:,c], q) for every image, channel and q (NumPy 2.2.6 float32 arithmetic,
+ * S6:196-197,216-217): d_out [batch][3][nq] float32.  q in percent. */
+int uwie_percentiles_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, int W, const double *q_percent, int nq,
+                         float *d_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* enhance_contrast / white_balance (S6:191-199, 211-219): clip((x-lo)/(hi-lo+1e-6),0,1). */
+int uwie_stretch_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, double lo_percent,
+                     double hi_percent, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* gamma_correction: mode 1 = x**g (S6:222-224), mode 2 = clip(x**(1/g),0,1) (ES:276-285). */
+int uwie_gamma_f32(uwie_ctx *ctx, const float *d_img, float *d_out, size_t n, double g, int mode, void *stream);
+
+/* apply_clahe (S6:202-208): (x*255).astype(u8) -> RGB2LAB -> CLAHE(L) -> LAB2RGB -> /255 float32. */
+int uwie_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, double clip_limit,
+                   int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* the OpenCV primitives on their own (u8 in, u8 out) */
+int uwie_rgb2gray_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_gray, size_t npixels, int gray_shift,
+                     void *stream);
+int uwie_rgb2lab_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_lab, size_t npixels, void *stream);
+int uwie_lab2rgb_u8(uwie_ctx *ctx, const uint8_t *d_lab, uint8_t *d_rgb, size_t npixels, void *stream);
+int uwie_clahe_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out, int batch, int H, int W, double clip_limit,
+                  int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream);
+/* cv2.Canny(gray, low, high) (S6:150): edge map (0/255) [batch][H][W]. */
+int uwie_canny_u8(uwie_ctx *ctx, const uint8_t *d_gray, uint8_t *d_edges, int batch, int H, int W, int low, int high,
+                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* cv2.equalizeHist per plane (ES:343): [batch][H][W]. */
+int uwie_equalize_hist_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out, int batch, int H, int W,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWIE_H_ */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the C ABI: the library builds/loads and exports every symbol include/uwie.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import underwater_image_enhancement_amd as uw
+from underwater_image_enhancement_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return uw.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "uwie.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uwie_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/uwie.h but not exported by libuwie.so"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_params_struct_matches_header_and_reference_defaults(lib):
+    # six_stadigy.py:230-285
+    want = {1: (0.3, 20, 0.5, 5, 98, 3.0, 1.5), 2: (0.5, 15, 0.5, 15, 95, 2.0, None), 3: (0.7, 10, 0.1, 20, 85, 0.0, None)}
+    for k, (omega, ks, eps, lo, hi, clip, gamma) in want.items():
+        p = uw.UwieParams()
+        assert lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, k) == 0
+        assert (round(p.omega, 6), p.gf_ksize, p.gf_eps, p.L_low, p.L_high, p.clip_limit) == (omega, ks, eps, lo, hi, clip)
+        assert p.cast_correct == 1 and p.forced_cast == -1 and p.gray_shift == 15 and p.min_size == 1
+        assert (p.tiles_x, p.tiles_y) == (8, 8)
+        if gamma:
+            assert p.gamma == gamma and p.apply_gamma == 1
+    p = uw.UwieParams()
+    assert lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, 3) == 0 and p.wb_percentile == 2
+    assert lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, 4) == 0
+    assert (p.clip_limit, p.L_low, p.L_high, p.wb_percentile, p.gamma) == (4.0, 10, 95, 3, 1.3)
+    # enhancement_strategies.py in-code defaults (:356-372, :382-395, :428-441) and the fixed eps (:209)
+    for name, (omega, ks, lo, hi) in {"strong_dehazing": (0.5, 15, 10, 95), "medium_dehazing": (0.6, 20, 15, 92),
+                                      "light_enhancement": (0.4, 10, 15, 95)}.items():
+        assert lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name]) == 0
+        assert (round(p.omega, 6), p.gf_ksize, p.L_low, p.L_high, p.gf_eps, p.cast_correct) == (omega, ks, lo, hi, 0.001, 0)
+    assert lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, 7) != 0
+    assert b"unknown strategy" in lib.uwie_last_error()
+    assert lib.uwie_params_init(ctypes.byref(p), 9, 1) != 0
+
+
+def test_workspace_sizes(lib):
+    p = uw.UwieParams()
+    lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, 2)
+    small = lib.uwie_workspace_bytes(1, 480, 640, ctypes.byref(p))
+    big = lib.uwie_workspace_bytes(64, 2160, 3840, ctypes.byref(p))
+    assert 0 < small < big < 288 * 2**30  # fits one MI355X
+    assert lib.uwie_workspace_bytes(0, 480, 640, ctypes.byref(p)) == 0
+    assert lib.uwie_workspace_bytes(1, -1, 640, ctypes.byref(p)) == 0
+    lib.uwie_params_init(ctypes.byref(p), _lib.SURFACE_SIX, 6)
+    assert lib.uwie_workspace_bytes(1, 480, 640, ctypes.byref(p)) <= small
+
+
+def test_null_arguments_are_rejected_without_a_gpu(lib):
+    assert lib.uwie_enhance_u8(None, None, None, None, 1, 8, 8, None, None, 0, None) == -1
+    assert lib.uwie_params_init(None, 0, 1) == -1
+    assert lib.uwie_rgb2lab_u8(None, None, None, 0, None) == -1
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(uw.UwieError):
+        uw.get_device(0)
+    import numpy as np
+
+    with pytest.raises(uw.UwieError):
+        uw.enhance(np.zeros((8, 8, 3), np.uint8))

@@ -1,0 +1,93 @@
+"""GPU parity of the whole pipeline: uwie_enhance_u8 (all six six_stadigy.py strategies) against the CPU oracle.
+
+The bar is <= 1 LSB on uint8 (BASELINE.json); the tests additionally report how many pixels differ at all.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_stages import frames_for_tests
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uw():
+    import underwater_image_enhancement_amd as uw
+
+    return uw
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import uwie_oracle
+
+    return uwie_oracle
+
+
+def check_u8(got, want, what):
+    assert got.shape == want.shape and got.dtype == np.uint8
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1, f"{what}: max |delta| = {d.max()} LSB, {np.count_nonzero(d > 1)} pixels beyond 1 LSB"
+    return int(np.count_nonzero(d))
+
+
+@pytest.mark.parametrize("strategy", [1, 2, 3, 4, 5, 6])
+def test_enhance_matches_oracle(uw, orc, strategy):
+    frames = frames_for_tests(np.random.default_rng(4242))
+    frames.pop("tiny_5x7")
+    total = diff = 0
+    for name, u8 in frames.items():
+        got = uw.enhance(u8, strategy=strategy)
+        want = orc.enhance_u8(u8, strategy)
+        diff += check_u8(got, want, f"strategy {strategy} on {name}")
+        total += got.size
+    assert diff == 0, f"strategy {strategy}: {diff} of {total} bytes differ by 1 LSB"
+
+
+def test_enhance_640x480_canonical(uw, orc):
+    rng = np.random.default_rng(1000)
+    yy, xx = np.mgrid[0:480, 0:640]
+    field = 0.5 + 0.25 * (np.sin(xx / 61.0) * np.cos(yy / 47.0) + 0.5 * np.sin((xx + 2 * yy) / 113.0)) / 1.5
+    f = field[:, :, None] * np.array([0.45, 0.85, 0.80]) + rng.normal(0, 0.02, (480, 640, 3))
+    u8 = np.clip(np.floor(255 * f), 0, 255).astype(np.uint8)
+    got = uw.enhance(u8)
+    assert check_u8(got, orc.enhance_u8(u8, 2), "canonical 640x480") == 0
+
+
+def test_batch_equals_singles_and_torch_path(uw):
+    import torch
+
+    rng = np.random.default_rng(77)
+    batch = rng.integers(0, 256, (3, 61, 83, 3), dtype=np.uint8)
+    batch[1, :, :, 1] = np.minimum(batch[1, :, :, 1].astype(int) + 70, 255)
+    out = uw.enhance(batch)
+    for b in range(3):
+        assert np.array_equal(out[b], uw.enhance(batch[b]))
+    t = torch.from_numpy(batch).cuda()
+    out_t = uw.enhance(t)
+    assert out_t.is_cuda and np.array_equal(out_t.cpu().numpy(), out)
+
+
+def test_cast_correct_normal_is_identity(uw):
+    rng = np.random.default_rng(78)
+    u8 = rng.integers(0, 256, (50, 60, 3), dtype=np.uint8)  # neutral noise: detect_image_type -> "normal"
+    assert np.array_equal(uw.enhance(u8, cast_correct=True), uw.enhance(u8, cast_correct=False))
+
+
+def test_float_surface_mirrors_reference_api(uw, orc):
+    rng = np.random.default_rng(79)
+    u8 = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    u8[:, :, 1] = np.minimum(u8[:, :, 1].astype(int) + 80, 255)
+    x = orc.normalise_u8(u8)
+    kind = uw.detect_image_type(x)
+    assert kind == orc.classify_cast(x) == "greenish"
+    xc = uw.color_correction(x, kind)
+    assert np.array_equal(xc, orc.correct_cast(x, kind))
+    assert uw.color_correction(x, "normal") is x
+    y = uw.SixStrategies.strategy2_medium_dehazing(xc)
+    want = orc.SixStrategyOracle.strategy(2, orc.correct_cast(x, kind))
+    assert y.dtype == np.float32 and np.array_equal(y, want)
+    with pytest.raises(ValueError):
+        uw.SixStrategies.strategy2_medium_dehazing(rng.random((8, 8, 3)).astype(np.float32))
+    with pytest.raises(ValueError):
+        uw.EnhancementStrategies.apply_strategy(x, "no_such_strategy", {})

@@ -1,0 +1,12 @@
+"""MI355X-native underwater image enhancement: hand-written HIP kernels (gfx950) behind the reference's API.
+
+Importing this package does not touch the GPU; the first call into :mod:`api` loads ``lib/libuwie.so`` and
+fails loudly when it (or a ROCm device) is missing -- there is no CPU fallback.
+"""
+from ._lib import UwieError, UwieParams, build, load  # noqa: F401
+from .api import (EnhancementStrategies, SixStrategies, color_correction, detect_image_type,  # noqa: F401
+                  enhance)
+from .runtime import Device, get_device  # noqa: F401
+
+__all__ = ["enhance", "SixStrategies", "EnhancementStrategies", "detect_image_type", "color_correction", "Device",
+           "get_device", "UwieError", "UwieParams", "build", "load"]

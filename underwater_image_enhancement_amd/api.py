@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's enhancement API, driving the HIP kernels.
+
+Reference surfaces mirrored here (same names, argument meaning and error behaviour):
+
+* ``enhance(frame_u8)``                         -- the canonical ``enhance(img) -> img`` of SURVEY.md section 8:
+  ``six_stadigy.py:406`` (u8 -> float32/255), ``:409-413`` (cast detection + correction),
+  ``:427`` (``strategyN``), ``:430`` (``(y*255).astype(uint8)``);
+* ``SixStrategies.strategy1_strong_dehazing`` ... ``strategy6_histogram_eq``, ``detect_image_type``,
+  ``color_correction``                           -- ``six_stadigy.py:230-285,292-323``;
+* ``EnhancementStrategies.apply_strategy(img, name, params)`` -- ``enhancement_strategies.py:477-508``.
+
+Float images handed to these functions must be u8-derived (``u8.astype(float32)/255`` possibly followed by
+``color_correction``), which is what every caller in the reference passes (``six_stadigy.py:406``,
+``main.py:108``): the device path starts from the u8 frame.  Anything else raises ``ValueError``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .runtime import Device, get_device
+
+_F255 = np.float32(255.0)
+_ATTEN = np.float32(0.85)
+
+
+def _as_batch_u8(frames, dev: Device):
+    """numpy/torch, [H,W,3] or [B,H,W,3] uint8 -> (cuda uint8 [B,H,W,3], was_numpy, was_single)."""
+    was_numpy = isinstance(frames, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(frames)) if was_numpy else frames
+    if t.dtype != torch.uint8:
+        raise TypeError(f"expected uint8 frames, got {t.dtype}")
+    single = t.dim() == 3
+    if single:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[-1] != 3:
+        raise ValueError(f"expected [H,W,3] or [B,H,W,3], got {tuple(t.shape)}")
+    if t.numel() == 0:
+        raise ValueError("empty image")
+    return t.to(dev.torch_device).contiguous(), was_numpy, single
+
+
+def _finish(t, was_numpy, single):
+    if single:
+        t = t[0]
+    return t.cpu().numpy() if was_numpy else t
+
+
+def enhance(frames, strategy: int = 2, cast_correct: bool = True, device: int | None = None, return_float: bool = False,
+            **overrides):
+    """Canonical ``enhance(u8 RGB) -> u8 RGB`` (six_stadigy.py:406-431) for one frame or a batch.
+
+    ``frames``: uint8 ``[H,W,3]`` / ``[B,H,W,3]``, NumPy (copied to HBM and back) or a torch ROCm tensor (stays on
+    the device).  ``strategy`` selects ``strategy1..6`` (default 2, medium dehazing).  ``overrides`` set
+    ``uwie_params`` fields (e.g. ``omega=0.6, gf_ksize=20``).
+    """
+    dev = get_device(device)
+    batch, was_numpy, single = _as_batch_u8(frames, dev)
+    p = dev.params(_lib.SURFACE_SIX, int(strategy), cast_correct=int(bool(cast_correct)), **overrides)
+    out, outf = dev.enhance_u8(batch, p, want_float=return_float)
+    return _finish(outf if return_float else out, was_numpy, single)
+
+
+# ------------------------------------------------------------------ float <-> u8 bridging
+def _recover_u8(img):
+    """Invert ``u8.astype(float32)/255`` [+ ``color_correction``] exactly; returns (u8 frame, cast kind)."""
+    x = np.asarray(img)
+    if x.ndim != 3 or x.shape[2] != 3:
+        raise ValueError(f"expected an HxWx3 image, got {x.shape}")
+    if x.size == 0:
+        raise ValueError("empty image")
+    x32 = x.astype(np.float32)
+    if x.dtype != np.float32 and not np.array_equal(x32.astype(x.dtype), x):
+        raise ValueError("float image is not float32-representable u8/255 data")
+    table = np.arange(256, dtype=np.float32) / _F255
+    for kind, chan in (("normal", None), ("greenish", 1), ("bluish", 2)):
+        ok, u8 = True, np.empty(x.shape, np.uint8)
+        for c in range(3):
+            lut = table * _ATTEN if c == chan else table
+            idx = np.clip(np.searchsorted(lut, x32[:, :, c]), 0, 255)
+            if not np.array_equal(lut[idx], x32[:, :, c]):
+                ok = False
+                break
+            u8[:, :, c] = idx
+        if ok:
+            return u8, kind
+    raise ValueError("float image is not u8-derived (u8/255, optionally colour-corrected): unsupported input")
+
+
+def detect_image_type(img, device: int | None = None) -> str:
+    """six_stadigy.py:292-302 on a u8-derived float image (or a u8 frame)."""
+    dev = get_device(device)
+    u8 = img if np.asarray(img).dtype == np.uint8 else _recover_u8(img)[0]
+    kind, _ = dev.cast_classify(dev.tensor(u8[None]))
+    return _lib.CAST_KINDS[int(kind[0])]
+
+
+def color_correction(img, image_type: str, device: int | None = None):
+    """six_stadigy.py:305-323.  ``"normal"`` returns the input object itself, like the reference."""
+    if image_type not in ("greenish", "bluish"):
+        return img
+    dev = get_device(device)
+    u8, kind = _recover_u8(img)
+    if kind != "normal":
+        raise ValueError("image is already colour-corrected")
+    k = torch.tensor([_lib.CAST_KINDS.index(image_type)], dtype=torch.int32, device=dev.torch_device)
+    return dev.normalise_correct(dev.tensor(u8[None]), k)[0].cpu().numpy()
+
+
+class SixStrategies:
+    """Mirror of ``six_stadigy.EnhancementStrategies`` (strategy1..6: float32 HxWx3 in [0,1] -> float32 HxWx3)."""
+
+    device: int | None = None
+
+    @classmethod
+    def _run(cls, number, img):
+        dev = get_device(cls.device)
+        u8, kind = _recover_u8(img)
+        # a colour-corrected input is replayed on the device from its u8 frame through a forced cast kind
+        p = dev.params(_lib.SURFACE_SIX, number, cast_correct=0, forced_cast=_lib.CAST_KINDS.index(kind) or -1)
+        _, outf = dev.enhance_u8(dev.tensor(u8[None]), p, want_float=True)
+        return outf[0].cpu().numpy()
+
+    @classmethod
+    def strategy1_strong_dehazing(cls, img):
+        return cls._run(1, img)
+
+    @classmethod
+    def strategy2_medium_dehazing(cls, img):
+        return cls._run(2, img)
+
+    @classmethod
+    def strategy3_light_dehazing(cls, img):
+        return cls._run(3, img)
+
+    @classmethod
+    def strategy4_clahe_enhancement(cls, img):
+        return cls._run(4, img)
+
+    @classmethod
+    def strategy5_white_balance(cls, img):
+        return cls._run(5, img)
+
+    @classmethod
+    def strategy6_histogram_eq(cls, img):
+        return cls._run(6, img)
+
+
+class EnhancementStrategies:
+    """Mirror of ``enhancement_strategies.EnhancementStrategies.apply_strategy`` (ES:477-508)."""
+
+    device: int | None = None
+    swallow_errors = True  # ES:503-508 prints the failure and returns the input image
+
+    @classmethod
+    def apply_strategy(cls, img, strategy_name, params):
+        if strategy_name not in _lib.DICT_STRATEGIES:
+            raise ValueError(f"未知策略: {strategy_name}")
+        try:
+            return cls._run(img, strategy_name, params)
+        except Exception as exc:  # noqa: BLE001 - mirrors the reference's blanket except
+            if not cls.swallow_errors:
+                raise
+            print(f"策略 {strategy_name} 執行失敗: {exc}")
+            return img
+
+    @classmethod
+    def _run(cls, img, name, params):
+        dev = get_device(cls.device)
+        u8, kind = _recover_u8(img)
+        if kind != "normal":
+            raise ValueError("colour-corrected input is not supported on the dict surface")
+        over = {}
+        for key, field in (("omega", "omega"), ("guided_radius", "gf_ksize"), ("L_low", "L_low"), ("L_high", "L_high"),
+                           ("clip_limit", "clip_limit"), ("gamma", "gamma")):
+            if key in params:
+                over[field] = params[key]
+        if "tile_grid_size" in params:
+            over["tiles_x"], over["tiles_y"] = (int(v) for v in params["tile_grid_size"])
+        over["apply_gamma"] = int(bool(params.get("apply_gamma", False)))
+        p = dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], **over)
+        _, outf = dev.enhance_u8(dev.tensor(u8[None]), p, want_float=True)
+        return outf[0].cpu().numpy()

@@ -1,0 +1,469 @@
+// C ABI of libuwie.so (include/uwie.h): context, parameter defaults, workspace sizing, the per-stage entry points
+// and the strategy pipelines.  Everything here only enqueues kernels on the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace uwie {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+bool shape_ok(int B, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1) return false;
+    const long long npx = (long long)H * W;
+    return npx < (1ll << 30) && (long long)B * npx < (1ll << 40);
+}
+
+#define UWIE_CHECK_SHAPE(B, H, W) UWIE_REQUIRE(shape_ok(B, H, W), "batch/H/W out of range")
+#define UWIE_CHECK_WS(need)                                                                           \
+    do {                                                                                              \
+        if ((need) > 0 && (!d_workspace || workspace_bytes < (need))) {                               \
+            set_error("workspace too small: need %zu bytes, got %zu", (size_t)(need), workspace_bytes); \
+            return UWIE_E_WORKSPACE;                                                                  \
+        }                                                                                             \
+    } while (0)
+#define UWIE_TRY(call)            \
+    do {                          \
+        int _rc = (call);         \
+        if (_rc != UWIE_OK) return _rc; \
+    } while (0)
+
+// Buffers of one enhance() call, carved from the caller's workspace.
+struct Pipe {
+    int32_t *kind;
+    float *A;
+    float *pct;
+    float *F;       // float32 HWC working image
+    uint8_t *gray;
+    float *t0;
+    double *t;
+    void *scratch;
+    size_t scratch_bytes;
+};
+
+size_t max5(size_t a, size_t b, size_t c, size_t d, size_t e)
+{
+    size_t m = a;
+    if (b > m) m = b;
+    if (c > m) m = c;
+    if (d > m) m = d;
+    if (e > m) m = e;
+    return m;
+}
+
+bool dehazes(const uwie_params *p)
+{
+    if (p->surface == UWIE_SURFACE_SIX) return p->strategy >= 1 && p->strategy <= 3;
+    return p->strategy >= UWIE_DICT_STRONG_DEHAZING && p->strategy <= UWIE_DICT_LIGHT_ENHANCEMENT;
+}
+
+Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
+{
+    Pipe P{};
+    const size_t n = (size_t)s.B * s.npx();
+    P.kind = c.take<int32_t>(s.B);
+    P.A = c.take<float>((size_t)s.B * 3);
+    P.pct = c.take<float>((size_t)s.B * 3 * kMaxPct);
+    P.F = c.take<float>(n * 3);
+    const bool dz = !p || dehazes(p);
+    if (dz) {
+        P.gray = c.take<uint8_t>(n);
+        P.t0 = c.take<float>(n);
+        P.t = c.take<double>(n);
+    }
+    const int tx = p ? p->tiles_x : 8, ty = p ? p->tiles_y : 8;
+    P.scratch_bytes = max5(cast_ws_bytes(s), dz ? airlight_ws_bytes(s) : 0, dz ? guided_ws_bytes(s) : 0,
+                           select_ws_bytes(s), clahe_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8));
+    P.scratch = c.take<char>(P.scratch_bytes);
+    return P;
+}
+
+int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipStream_t st)
+{
+    const double q[2] = {lo, hi};
+    UWIE_TRY(launch_percentiles_f32(P.F, 0, s, q, 2, P.pct, P.scratch, st));
+    return launch_stretch_apply_f32(P.F, P.pct, 2, 0, 1, eps, P.F, s, st);
+}
+
+int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, hipStream_t st)
+{
+    const size_t n3 = (size_t)s.B * s.npx() * 3;
+    const int32_t *kind = nullptr;
+    if (p->forced_cast >= 0) {
+        UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
+        kind = P.kind;
+    } else if (p->cast_correct) {
+        UWIE_TRY(launch_cast_classify(ctx, d_in, s, P.kind, nullptr, P.scratch, st));
+        kind = P.kind;
+    }
+    const float eps = 1e-6f;  // six_stadigy.py:198,218
+    const int k = p->strategy;
+    if (k >= 1 && k <= 3) {
+        UWIE_TRY(launch_quant_gray(d_in, kind, P.gray, s, p->gray_shift, st));
+        UWIE_TRY(launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
+        UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
+        UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+        UWIE_TRY(launch_restore(d_in, kind, P.A, P.t, s, P.F, st));
+        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
+        if (k == 3) {
+            UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
+        } else {
+            UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+            if (k == 1) UWIE_TRY(launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st));
+        }
+        return UWIE_OK;
+    }
+    UWIE_TRY(launch_normalise_correct(d_in, kind, P.F, s, st));
+    if (k == 4) {
+        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
+        UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
+    } else if (k == 5) {
+        UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
+        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
+        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+    } else {
+        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
+        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+    }
+    return launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st);
+}
+
+int check_params(const uwie_params *p)
+{
+    UWIE_REQUIRE(p != nullptr, "params is NULL");
+    UWIE_REQUIRE(p->surface == UWIE_SURFACE_SIX || p->surface == UWIE_SURFACE_DICT, "unknown surface");
+    if (p->surface == UWIE_SURFACE_SIX) UWIE_REQUIRE(p->strategy >= 1 && p->strategy <= 6, "unknown strategy");
+    else UWIE_REQUIRE(p->strategy >= 0 && p->strategy <= 4, "unknown strategy");
+    UWIE_REQUIRE(p->gray_shift == 14 || p->gray_shift == 15, "gray_shift must be 14 or 15");
+    UWIE_REQUIRE(p->forced_cast >= -1 && p->forced_cast <= 2, "forced_cast must be -1 or a UWIE_CAST_* kind");
+    UWIE_REQUIRE(p->min_size >= 1, "min_size must be >= 1");
+    UWIE_REQUIRE(p->tiles_x >= 1 && p->tiles_y >= 1 && p->tiles_x * p->tiles_y <= 4096, "bad CLAHE tile grid");
+    if (dehazes(p)) UWIE_REQUIRE(p->gf_ksize >= 1 && p->gf_ksize <= 1024, "guided-filter width out of range");
+    return UWIE_OK;
+}
+
+}  // namespace
+}  // namespace uwie
+
+using namespace uwie;
+
+extern "C" {
+
+const char *uwie_last_error(void) { return g_err; }
+const char *uwie_version(void) { return "uwie 0.1 (gfx950)"; }
+
+int uwie_create(int device, uwie_ctx **out_ctx)
+{
+    UWIE_REQUIRE(out_ctx != nullptr, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device available (libuwie has no CPU path)");
+        return UWIE_E_NODEVICE;
+    }
+    UWIE_REQUIRE(device >= 0 && device < count, "device index out of range");
+    UWIE_HIP_CHECK(hipSetDevice(device));
+    uwie_ctx *ctx = new uwie_ctx();
+    ctx->device = device;
+    LabTables *lab = new LabTables();
+    CastTables *cast = new CastTables();
+    build_lab_tables(lab);
+    build_cast_tables(cast);
+    hipError_t e = hipMalloc((void **)&ctx->d_lab, sizeof(LabTables));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cast, sizeof(CastTables));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_lab, lab, sizeof(LabTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_cast, cast, sizeof(CastTables), hipMemcpyHostToDevice);
+    delete lab;
+    delete cast;
+    if (e != hipSuccess) {
+        set_error("context table upload failed: %s", hipGetErrorString(e));
+        uwie_destroy(ctx);
+        return UWIE_E_HIP;
+    }
+    *out_ctx = ctx;
+    return UWIE_OK;
+}
+
+void uwie_destroy(uwie_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->d_lab) (void)hipFree(ctx->d_lab);
+    if (ctx->d_cast) (void)hipFree(ctx->d_cast);
+    delete ctx;
+}
+
+int uwie_params_init(uwie_params *p, int surface, int strategy)
+{
+    UWIE_REQUIRE(p != nullptr, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->surface = surface;
+    p->strategy = strategy;
+    p->gray_shift = 15;
+    p->min_size = 1;
+    p->tiles_x = p->tiles_y = 8;
+    p->wb_percentile = -1.0;
+    p->gamma = 1.2;
+    p->forced_cast = -1;
+    if (surface == UWIE_SURFACE_SIX) {
+        p->cast_correct = 1;
+        switch (strategy) {  // six_stadigy.py:230-285
+        case 1: p->omega = 0.3f; p->gf_ksize = 20; p->gf_eps = 5e-1; p->L_low = 5; p->L_high = 98; p->clip_limit = 3.0; p->gamma = 1.5; p->apply_gamma = 1; break;
+        case 2: p->omega = 0.5f; p->gf_ksize = 15; p->gf_eps = 5e-1; p->L_low = 15; p->L_high = 95; p->clip_limit = 2.0; break;
+        case 3: p->omega = 0.7f; p->gf_ksize = 10; p->gf_eps = 1e-1; p->L_low = 20; p->L_high = 85; p->wb_percentile = 2; break;
+        case 4: p->clip_limit = 4.0; p->L_low = 10; p->L_high = 95; p->wb_percentile = 3; p->gamma = 1.3; p->apply_gamma = 1; break;
+        case 5: p->wb_percentile = 2; p->L_low = 15; p->L_high = 90; p->clip_limit = 1.5; p->gamma = 1.2; p->apply_gamma = 1; break;
+        case 6: p->L_low = 5; p->L_high = 98; p->clip_limit = 3.5; p->gamma = 1.4; p->apply_gamma = 1; break;
+        default: set_error("unknown strategy %d", strategy); return UWIE_E_INVALID;
+        }
+        return UWIE_OK;
+    }
+    if (surface == UWIE_SURFACE_DICT) {
+        p->gf_eps = 0.001;  // estimate_transmission's default; callers never pass it (ES:209,354-358)
+        switch (strategy) {  // in-code defaults of ES:350-474
+        case UWIE_DICT_STRONG_DEHAZING: p->omega = 0.5f; p->gf_ksize = 15; p->L_low = 10; p->L_high = 95; break;
+        case UWIE_DICT_MEDIUM_DEHAZING: p->omega = 0.6f; p->gf_ksize = 20; p->L_low = 15; p->L_high = 92; break;
+        case UWIE_DICT_LIGHT_ENHANCEMENT: p->omega = 0.4f; p->gf_ksize = 10; p->L_low = 15; p->L_high = 95; break;
+        case UWIE_DICT_CLAHE_ENHANCEMENT: p->clip_limit = 2.0; p->L_low = 20; p->L_high = 85; break;
+        case UWIE_DICT_HISTOGRAM_EQUALIZATION: p->L_low = 10; p->L_high = 95; break;
+        default: set_error("unknown strategy %d", strategy); return UWIE_E_INVALID;
+        }
+        return UWIE_OK;
+    }
+    set_error("unknown surface %d", surface);
+    return UWIE_E_INVALID;
+}
+
+size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
+{
+    if (!shape_ok(batch, H, W)) return 0;
+    const Shape s{batch, H, W};
+    Carver c(nullptr);
+    carve_pipe(c, s, p);
+    // stage entry points carve their own (smaller) layouts from the same buffer
+    size_t stage = canny_ws_bytes(s) + (size_t)batch * sizeof(Region) + 256;
+    const size_t gf = guided_ws_bytes(s);
+    if (gf > stage) stage = gf;
+    const size_t cl = clahe_ws_bytes(s, p && p->tiles_x > 0 ? p->tiles_x : 8, p && p->tiles_y > 0 ? p->tiles_y : 8);
+    if (cl > stage) stage = cl;
+    const size_t al = airlight_ws_bytes(s) + (size_t)batch * s.npx() + 256;
+    if (al > stage) stage = al;
+    return c.total() > stage ? c.total() : stage;
+}
+
+int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float *d_out_f32, int batch, int H, int W,
+                    const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && (d_out_u8 || d_out_f32), "enhance: NULL context or image pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_TRY(check_params(p));
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    Pipe P = carve_pipe(c, s, p);
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    if (p->surface == UWIE_SURFACE_SIX) {
+        UWIE_TRY(run_six(ctx, d_in, s, p, P, st));
+    } else {
+        set_error("the enhancement_strategies.py (dict) surface is not wired into uwie_enhance_u8 yet");
+        return UWIE_E_INVALID;
+    }
+    const size_t n3 = (size_t)batch * s.npx() * 3;
+    if (d_out_u8) UWIE_TRY(launch_quantise_u8(P.F, d_out_u8, n3, st));
+    if (d_out_f32) UWIE_HIP_CHECK(hipMemcpyAsync(d_out_f32, P.F, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UWIE_OK;
+}
+
+/* ---------------------------------------------------------------- stage entry points */
+
+int uwie_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int W, int32_t *d_kind, float *d_mean_rgb,
+                       void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && (d_kind || d_mean_rgb), "cast_classify: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(cast_ws_bytes(s));
+    return launch_cast_classify(ctx, d_in, s, d_kind, d_mean_rgb, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_normalise_correct(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, float *d_out_f32, int batch, int H,
+                           int W, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_out_f32, "normalise_correct: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    return launch_normalise_correct(d_in, d_kind, d_out_f32, Shape{batch, H, W}, (hipStream_t)stream);
+}
+
+int uwie_atmospheric_light(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, int batch, int H, int W,
+                           const uwie_params *p, float *d_A, void *d_trace, void *d_workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_A && p, "atmospheric_light: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(p->min_size >= 1 && (p->gray_shift == 14 || p->gray_shift == 15), "atmospheric_light: bad params");
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    uint8_t *gray = c.take<uint8_t>((size_t)batch * s.npx());
+    void *ws = c.take<char>(airlight_ws_bytes(s));
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    UWIE_TRY(launch_quant_gray(d_in, d_kind, gray, s, p->gray_shift, st));
+    return launch_airlight(ctx, d_in, d_kind, gray, s, p->min_size, d_A, d_trace, ws, st);
+}
+
+int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, int batch, int H,
+                           int W, const uwie_params *p, float *d_t0, uint8_t *d_gray, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_A && p && (d_t0 || d_gray), "transmission_init: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    hipStream_t st = (hipStream_t)stream;
+    const bool six = p->surface == UWIE_SURFACE_SIX;
+    if (d_t0) UWIE_TRY(launch_trans_init(d_in, d_kind, d_A, s, p->omega, six ? 1e-6f : 1e-10f, six ? 1 : 0, d_t0, st));
+    if (d_gray) UWIE_TRY(launch_quant_gray(d_in, d_kind, d_gray, s, p->gray_shift, st));
+    return UWIE_OK;
+}
+
+int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int batch, int H, int W, int ksize,
+                        void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_src && d_dst, "box_filter: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "box_filter: ksize out of range");
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(box_ws_bytes(s));
+    return launch_box_filter_f64(d_src, d_dst, s, ksize, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
+                       double eps, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_gray && d_t0 && d_t, "guided_filter: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "guided_filter: ksize out of range");
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(guided_ws_bytes(s));
+    return launch_guided(d_gray, d_t0, s, ksize, eps, d_t, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t,
+                 int batch, int H, int W, float *d_out_f32, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_A && d_t && d_out_f32, "restore: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    return launch_restore(d_in, d_kind, d_A, d_t, Shape{batch, H, W}, d_out_f32, (hipStream_t)stream);
+}
+
+int uwie_percentiles_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, int W, const double *q_percent, int nq,
+                         float *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && q_percent && d_out, "percentiles: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(select_ws_bytes(s));
+    return launch_percentiles_f32(d_img, 0, s, q_percent, nq, d_out, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_stretch_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, double lo_percent,
+                     double hi_percent, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && d_out, "stretch: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    float *pct = c.take<float>((size_t)batch * 3 * 2);
+    void *ws = c.take<char>(select_ws_bytes(s));
+    UWIE_CHECK_WS(c.total());
+    const double q[2] = {lo_percent, hi_percent};
+    hipStream_t st = (hipStream_t)stream;
+    UWIE_TRY(launch_percentiles_f32(d_img, 0, s, q, 2, pct, ws, st));
+    return launch_stretch_apply_f32(d_img, pct, 2, 0, 1, 1e-6f, d_out, s, st);
+}
+
+int uwie_gamma_f32(uwie_ctx *ctx, const float *d_img, float *d_out, size_t n, double g, int mode, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && d_out, "gamma: NULL pointer");
+    return launch_gamma_f32(d_img, d_out, n, g, mode, (hipStream_t)stream);
+}
+
+int uwie_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, double clip_limit,
+                   int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && d_out, "clahe: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(tiles_x >= 1 && tiles_y >= 1 && tiles_x * tiles_y <= 4096, "clahe: bad tile grid");
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(clahe_ws_bytes(s, tiles_x, tiles_y));
+    return launch_clahe_f32(ctx, d_img, d_out, s, clip_limit, tiles_x, tiles_y, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_rgb2gray_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_gray, size_t npixels, int gray_shift, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_rgb && d_gray, "rgb2gray: NULL pointer");
+    UWIE_REQUIRE(gray_shift == 14 || gray_shift == 15, "gray_shift must be 14 or 15");
+    return launch_rgb2gray_u8(d_rgb, d_gray, npixels, gray_shift, (hipStream_t)stream);
+}
+
+int uwie_rgb2lab_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_lab, size_t npixels, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_rgb && d_lab, "rgb2lab: NULL pointer");
+    return launch_rgb2lab_u8(ctx, d_rgb, d_lab, npixels, (hipStream_t)stream);
+}
+
+int uwie_lab2rgb_u8(uwie_ctx *ctx, const uint8_t *d_lab, uint8_t *d_rgb, size_t npixels, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_lab && d_rgb, "lab2rgb: NULL pointer");
+    return launch_lab2rgb_u8(ctx, d_lab, d_rgb, npixels, (hipStream_t)stream);
+}
+
+int uwie_clahe_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out, int batch, int H, int W, double clip_limit,
+                  int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_plane && d_out, "clahe_u8: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(tiles_x >= 1 && tiles_y >= 1 && tiles_x * tiles_y <= 4096, "clahe: bad tile grid");
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(clahe_ws_bytes(s, tiles_x, tiles_y));
+    return launch_clahe_plane_u8(d_plane, d_out, s, clip_limit, tiles_x, tiles_y, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_canny_u8(uwie_ctx *ctx, const uint8_t *d_gray, uint8_t *d_edges, int batch, int H, int W, int low, int high,
+                  void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_gray && d_edges, "canny: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    if (low > high) { const int t = low; low = high; high = t; }
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    Region *regs = c.take<Region>(batch);
+    void *ws = c.take<char>(canny_ws_bytes(s));
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    UWIE_TRY(launch_make_full_regions(regs, s, st));
+    return launch_canny(d_gray, s, regs, batch, H, W, low, high, nullptr, d_edges, ws, st);
+}
+
+int uwie_equalize_hist_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out, int batch, int H, int W,
+                          void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_plane && d_out, "equalize_hist: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS((size_t)batch * 256 + 256);
+    return launch_equalize_hist_u8(d_plane, d_out, s, d_workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// Shared declarations of libuwie.so (gfx950 only; no CPU fallback anywhere in this library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/uwie.h"
+
+namespace uwie {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char *fmt, ...);
+#define UWIE_HIP_CHECK(expr)                                                            \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::uwie::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return UWIE_E_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+#define UWIE_LAUNCH_CHECK() UWIE_HIP_CHECK(hipGetLastError())
+#define UWIE_REQUIRE(cond, msg)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::uwie::set_error("%s", msg);       \
+            return UWIE_E_INVALID;              \
+        }                                       \
+    } while (0)
+
+// ---------------------------------------------------------------- constant tables (device copies owned by the context)
+constexpr int kCastBinadeMin = -2;  // sequential-mean emulation handles accumulators >= 2^-2 in closed form
+constexpr int kCastBinades = 34;    // e = -2 .. 31
+
+struct LabTables {           // OpenCV's integer sRGB<->Lab tables (see tables.cpp)
+    uint16_t gamma[256];     // sRGBGammaTab_b
+    uint16_t cbrt[3072];     // LabCbrtTab_b
+    int32_t fwd[9];          // RGB->XYZ/white, 12-bit
+    uint8_t invgamma[4096];  // sRGBInvGammaTab_b (values <= 255)
+    int32_t ltoyf[512];      // LabToYF_b
+    int32_t abtoxz[36864];   // abToXZ_b
+    int32_t inv[9];          // XYZ*white->RGB, 12-bit
+};
+
+struct CastTables {                         // rounding tables for the sequential float32 mean (k_entry.hip)
+    uint32_t R[kCastBinades][256];          // RN(x_k / ulp_e)
+    uint8_t tie[kCastBinades][256];         // 1 if x_k / ulp_e has fractional part exactly 1/2
+};
+
+void build_lab_tables(LabTables *t);
+void build_cast_tables(CastTables *t);
+
+}  // namespace uwie
+
+struct uwie_ctx {
+    int device;
+    uwie::LabTables *d_lab;
+    uwie::CastTables *d_cast;
+};
+
+namespace uwie {
+
+// ---------------------------------------------------------------- workspace carving
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *b) : base(static_cast<char *>(b)), off(0) {}
+    template <typename T>
+    T *take(size_t count)
+    {
+        off = (off + 255) & ~size_t(255);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return (off + 255) & ~size_t(255); }
+};
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// blocks of 256 threads for a grid-stride loop over n items
+static inline int grid_for(size_t n, size_t cap = 8192)
+{
+    size_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : (int)g;
+}
+
+// ---------------------------------------------------------------- region descriptor used by the Canny / quadtree kernels
+struct Region {  // a rectangle of image `img`; rows == 0 marks an inactive region
+    int32_t img, y0, x0, rows, cols;
+};
+
+// ---------------------------------------------------------------- stage launchers (each enqueues on `stream`, returns UWIE_*)
+struct Shape {
+    int B, H, W;
+    size_t npx() const { return (size_t)H * W; }
+};
+
+// k_entry.hip
+size_t cast_ws_bytes(Shape s);
+int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d_kind, float *d_mean, void *ws,
+                         hipStream_t st);
+int launch_set_kind(int32_t *d_kind, int B, int kind, hipStream_t st);
+int launch_normalise_correct(const uint8_t *d_in, const int32_t *d_kind, float *d_out, Shape s, hipStream_t st);
+int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int gray_shift,
+                      hipStream_t st);
+
+// k_airlight.hip
+size_t airlight_ws_bytes(Shape s);
+int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const uint8_t *d_gray, Shape s,
+                    int min_size, float *d_A, void *d_trace, void *ws, hipStream_t st);
+
+// k_canny.hip  (regions: device array of nreg Region; max_rows/max_cols bound every region)
+size_t canny_ws_bytes(Shape s);
+int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
+                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st);
+int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st);
+
+// k_guided.hip
+size_t guided_ws_bytes(Shape s);
+size_t box_ws_bytes(Shape s);
+int launch_trans_init(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, Shape s, float omega, float norm_eps,
+                      int pre_clip, float *d_t0, hipStream_t st);
+int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, void *ws, hipStream_t st);
+int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, void *ws,
+                  hipStream_t st);
+
+// k_select.hip
+constexpr int kMaxPct = 4;  // percentiles per call
+size_t select_ws_bytes(Shape s);
+// d_vals: float32 image, HWC ([B][H][W][3], planar = 0) or planar ([B][3][H][W], planar = 1); d_out [B][3][nq]
+int launch_percentiles_f32(const float *d_vals, int planar, Shape s, const double *q_percent, int nq, float *d_out,
+                           void *ws, hipStream_t st);
+
+// k_tail.hip
+int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
+                   float *d_out, hipStream_t st);
+// out = clip((x - lo) / (hi - lo + eps), 0, 1) with lo = d_pct[(b*3+c)*pct_stride + lo_idx], hi likewise
+int launch_stretch_apply_f32(const float *d_img, const float *d_pct, int pct_stride, int lo_idx, int hi_idx, float eps,
+                             float *d_out, Shape s, hipStream_t st);
+int launch_gamma_f32(const float *d_img, float *d_out, size_t n, double g, int mode, hipStream_t st);
+int launch_quantise_u8(const float *d_img, uint8_t *d_out, size_t n, hipStream_t st);
+
+// k_clahe.hip
+size_t clahe_ws_bytes(Shape s, int tx, int ty);
+int launch_rgb2gray_u8(const uint8_t *d_rgb, uint8_t *d_gray, size_t n, int shift, hipStream_t st);
+int launch_rgb2lab_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_lab, size_t n, hipStream_t st);
+int launch_lab2rgb_u8(uwie_ctx *ctx, const uint8_t *d_lab, uint8_t *d_rgb, size_t n, hipStream_t st);
+int launch_clahe_plane_u8(const uint8_t *d_plane, uint8_t *d_out, Shape s, double clip, int tx, int ty, void *ws,
+                          hipStream_t st);
+int launch_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, Shape s, double clip, int tx, int ty, void *ws,
+                     hipStream_t st);
+int launch_equalize_hist_u8(const uint8_t *d_plane, uint8_t *d_out, Shape s, void *ws, hipStream_t st);
+
+}  // namespace uwie

@@ -1,0 +1,90 @@
+// Device-side helpers shared by the kernels (gfx950: wave = 64 lanes).
+// The whole library is compiled with -ffp-contract=off: every float/double operation below rounds once,
+// in the order written, which is what makes the results reproduce NumPy's / OpenCV's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uwie {
+
+constexpr int kWave = 64;
+
+// x = u8/255 (six_stadigy.py:406, true float32 division), then the cast attenuation of
+// color_correction (six_stadigy.py:310,317: channel * 0.85, clip is a no-op for values in [0,1]).
+__device__ __forceinline__ float px_norm(uint32_t u) { return (float)u / 255.0f; }
+__device__ __forceinline__ float px_val(uint32_t u, bool attenuate)
+{
+    float x = (float)u / 255.0f;
+    return attenuate ? x * 0.85f : x;
+}
+// which channel color_correction attenuates for a cast kind (UWIE_CAST_*): greenish -> G, bluish -> B
+__device__ __forceinline__ bool px_atten(int kind, int c) { return kind != 0 && c == kind; }
+// (img * 255).astype(np.uint8): float32 product, truncation toward zero
+__device__ __forceinline__ uint32_t quant_u8(float x) { return (uint32_t)(int)(x * 255.0f) & 0xffu; }
+
+__device__ __forceinline__ uint32_t gray_fixed(uint32_t r, uint32_t g, uint32_t b, int shift)
+{
+    return shift == 15 ? (r * 9798u + g * 19235u + b * 3735u + 16384u) >> 15
+                       : (r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14;
+}
+
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
+{
+    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m)
+{
+    uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d)
+{
+    uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = shfl_up_u64(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+}  // namespace uwie

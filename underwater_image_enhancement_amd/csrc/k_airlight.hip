@@ -1,0 +1,388 @@
+// estimate_atmospheric_light (six_stadigy.py:49-113 == enhancement_strategies.py:77-144): greedy quadtree
+// descent.  Per level the four quadrants of the current block are scored with compute_Q
+// (six_stadigy.py:116-157) and the walk steps into the first maximum; the leaf's brightest pixel is A.
+//
+// compute_Q's float32 sums must reproduce NumPy's summation ORDER, because the argmax over the four scores
+// is discontinuous: `np.sum` over a (strided or contiguous) 2-D float32 array walks it in raster order in
+// buffer chunks of 8192 elements, sums each chunk with its pairwise routine (8 interleaved accumulators on
+// blocks of <=128, recursive halving above that) and adds the chunk results sequentially (measured, NumPy
+// 2.2.6).  One wavefront evaluates one chunk: for a full chunk lane l owns the l-th 128-element leaf and the
+// 64 leaf sums are combined by an xor-butterfly, which is exactly the recursion's tree; a ragged tail chunk
+// enumerates the recursion's leaves first and combines them in post-order.
+#include "common.h"
+#include "devutil.h"
+
+namespace uwie {
+
+namespace {
+
+constexpr int kNpChunk = 8192;  // NumPy's reduction buffer size (np.getbufsize())
+constexpr int kMaxLeaves = 192;
+constexpr int kMaxLevels = 32;
+
+struct TraceRec {  // matches the layout documented in uwie.h
+    int32_t y0, x0, rows, cols;
+    double score[4];
+};
+
+struct LevelBufs {
+    Region *blk;       // [B] current block
+    Region *regs;      // [4B] its quadrants (inactive when the block is a leaf)
+    float *csum;       // [4B][maxChunks][3] chunk sums
+    float *tot;        // [4B][3] sums
+    float *mean;       // [4B][3] means
+    float *vtot;       // [4B][3] sums of squared deviations
+    uint32_t *edges;   // [4B] Canny edge counts
+};
+
+__global__ void k_init_blocks(Region *blk, int B, int H, int W)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) blk[b] = Region{b, 0, 0, H, W};
+}
+
+__global__ void k_make_quadrants(const Region *__restrict__ blk, Region *__restrict__ regs, int B, int min_size)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const Region k = blk[b];
+    const bool leaf = k.rows <= min_size || k.cols <= min_size;  // six_stadigy.py:76
+    const int mr = k.rows / 2, mc = k.cols / 2;                 // six_stadigy.py:85-86
+    Region q[4] = {{b, k.y0, k.x0, mr, mc},
+                   {b, k.y0, k.x0 + mc, mr, k.cols - mc},
+                   {b, k.y0 + mr, k.x0, k.rows - mr, mc},
+                   {b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc}};
+    for (int i = 0; i < 4; ++i) {
+        if (leaf) q[i].rows = q[i].cols = 0;
+        regs[b * 4 + i] = q[i];
+    }
+}
+
+// value of element `e` (raster index inside region r) for channel c: x or (x - mean)^2
+template <bool VAR>
+struct Elem {
+    const uint8_t *img;
+    const float *xs;
+    int W, kind;
+    float mean[3];
+    __device__ __forceinline__ float get(const uint8_t *p, int c) const
+    {
+        float v = xs[p[c]];
+        if (px_atten(kind, c)) v = v * 0.85f;
+        if (VAR) {
+            const float d = v - mean[c];
+            v = d * d;
+        }
+        return v;
+    }
+};
+
+__device__ __forceinline__ float tree8(const float *r)
+{
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+// NumPy's pairwise_sum on a block of n <= 128 elements starting at raster element e0, three channels at once.
+template <bool VAR>
+__device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, float out[3])
+{
+    int ly = e0 / r.cols, lx = e0 % r.cols;
+    const uint8_t *p = el.img + ((size_t)(r.y0 + ly) * el.W + r.x0 + lx) * 3;
+    auto step = [&]() {
+        ++lx;
+        p += 3;
+        if (lx == r.cols) {
+            lx = 0;
+            p += (size_t)(el.W - r.cols) * 3;
+        }
+    };
+    if (n < 8) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int i = 0; i < n; ++i) {
+            a0 += el.get(p, 0);
+            a1 += el.get(p, 1);
+            a2 += el.get(p, 2);
+            step();
+        }
+        out[0] = a0; out[1] = a1; out[2] = a2;
+        return;
+    }
+    float acc[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c][j] = el.get(p, c);
+        step();
+    }
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c][j] += el.get(p, c);
+            step();
+        }
+    }
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) res[c] = tree8(acc[c]);
+    for (; i < n; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) res[c] += el.get(p, c);
+        step();
+    }
+    out[0] = res[0]; out[1] = res[1]; out[2] = res[2];
+}
+
+// One wavefront per (chunk, region).  csum[(reg*maxChunks + chunk)*3 + c] = pairwise sum of that chunk.
+template <bool VAR>
+__global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                     const Region *__restrict__ regs, const float *__restrict__ mean,
+                                                     int H, int W, int maxChunks, float *__restrict__ csum)
+{
+    const int reg = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
+    const Region r = regs[reg];
+    const int n = r.rows * r.cols;
+    const int c0 = ci * kNpChunk;
+    if (c0 >= n) return;
+    const int len = min(kNpChunk, n - c0);
+
+    __shared__ float xs[256];
+    __shared__ int leafOff[kMaxLeaves], leafLen[kMaxLeaves], nLeaf;
+    __shared__ float leafSum[3][kMaxLeaves];
+    __shared__ int fOff[32], fLen[32], fStage[32];
+    __shared__ float vals[3][32];
+    for (int i = lane; i < 256; i += 64) xs[i] = px_norm(i);
+    __syncthreads();
+
+    Elem<VAR> el;
+    el.img = in + (size_t)r.img * H * W * 3;
+    el.xs = xs;
+    el.W = W;
+    el.kind = kind ? kind[r.img] : 0;
+    if (VAR) {
+        el.mean[0] = mean[reg * 3 + 0];
+        el.mean[1] = mean[reg * 3 + 1];
+        el.mean[2] = mean[reg * 3 + 2];
+    }
+    float *out = csum + ((size_t)reg * maxChunks + ci) * 3;
+
+    if (len == kNpChunk) {
+        // balanced tree: 64 leaves of 128, lane = leaf, butterfly == recursive halving
+        float s[3];
+        leaf_sum3<VAR>(el, r, c0 + lane * 128, 128, s);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            s[0] += __shfl_xor(s[0], o);
+            s[1] += __shfl_xor(s[1], o);
+            s[2] += __shfl_xor(s[2], o);
+        }
+        if (lane == 0) { out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; }
+        return;
+    }
+    // ragged chunk: enumerate the recursion's leaves (pre-order == left-to-right order)
+    if (lane == 0) {
+        int sp = 0, nl = 0;
+        fOff[0] = 0; fLen[0] = len; sp = 1;
+        while (sp > 0) {
+            --sp;
+            const int off = fOff[sp], l = fLen[sp];
+            if (l <= 128) {
+                leafOff[nl] = off; leafLen[nl] = l; ++nl;
+            } else {
+                int n2 = l / 2;
+                n2 -= n2 % 8;
+                fOff[sp] = off + n2; fLen[sp] = l - n2; ++sp;  // right child (popped second)
+                fOff[sp] = off; fLen[sp] = n2; ++sp;           // left child (popped first)
+            }
+        }
+        nLeaf = nl;
+    }
+    __syncthreads();
+    for (int i = lane; i < nLeaf; i += 64) {
+        float s[3];
+        leaf_sum3<VAR>(el, r, c0 + leafOff[i], leafLen[i], s);
+        leafSum[0][i] = s[0]; leafSum[1][i] = s[1]; leafSum[2][i] = s[2];
+    }
+    __syncthreads();
+    // post-order combine, replaying the recursion; lanes 0..2 each own one channel's value stack,
+    // lane 0's frame stack drives all three (the tree shape does not depend on the channel)
+    if (lane == 0) {
+        int sp = 0, vsp = 0, next = 0;
+        fOff[0] = 0; fLen[0] = len; fStage[0] = 0; sp = 1;
+        while (sp > 0) {
+            const int t = sp - 1, l = fLen[t];
+            if (l <= 128) {
+                vals[0][vsp] = leafSum[0][next]; vals[1][vsp] = leafSum[1][next]; vals[2][vsp] = leafSum[2][next];
+                ++vsp; ++next; --sp;
+                continue;
+            }
+            int n2 = l / 2;
+            n2 -= n2 % 8;
+            if (fStage[t] == 0) {
+                fStage[t] = 1;
+                fOff[sp] = fOff[t]; fLen[sp] = n2; fStage[sp] = 0; ++sp;
+            } else if (fStage[t] == 1) {
+                fStage[t] = 2;
+                fOff[sp] = fOff[t] + n2; fLen[sp] = l - n2; fStage[sp] = 0; ++sp;
+            } else {
+                --vsp;
+                for (int c = 0; c < 3; ++c) vals[c][vsp - 1] = vals[c][vsp - 1] + vals[c][vsp];
+                --sp;
+            }
+        }
+        out[0] = vals[0][0]; out[1] = vals[1][0]; out[2] = vals[2][0];
+    }
+}
+
+// Sequential accumulation of the chunk sums (NumPy adds each buffer's pairwise result into the running total),
+// and for the first pass the mean: float32(float64(sum) / n) as numpy/_core/_methods.py:_mean does for a scalar result.
+template <bool VAR>
+__global__ void k_q_combine(const Region *__restrict__ regs, const float *__restrict__ csum, int nreg, int maxChunks,
+                            float *__restrict__ tot, float *__restrict__ mean)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nreg * 3) return;
+    const int reg = i / 3, c = i % 3;
+    const Region r = regs[reg];
+    const int n = r.rows * r.cols;
+    if (n == 0) return;
+    const int nch = (n + kNpChunk - 1) / kNpChunk;
+    float acc = 0.0f;
+    for (int k = 0; k < nch; ++k) acc = acc + csum[((size_t)reg * maxChunks + k) * 3 + c];
+    tot[i] = acc;
+    if (!VAR) mean[i] = (float)((double)acc / (double)n);
+}
+
+// compute_Q's final arithmetic (six_stadigy.py:134-155) and the greedy step (six_stadigy.py:100-111).
+__global__ void k_q_select(Region *__restrict__ blk, const Region *__restrict__ regs, const float *__restrict__ tot,
+                           const float *__restrict__ vtot, const uint32_t *__restrict__ edges, int B, int level,
+                           TraceRec *__restrict__ trace)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (regs[b * 4].rows == 0) return;  // leaf reached earlier
+    double best = 0.0;
+    int arg = 0;
+    double score[4];
+    for (int q = 0; q < 4; ++q) {
+        const Region r = regs[b * 4 + q];
+        const long long n = (long long)r.rows * r.cols;
+        const float *S = tot + (b * 4 + q) * 3, *V = vtot + (b * 4 + q) * 3;
+        const float t1 = ((S[0] + S[1]) + S[2]) / (float)(3 * n);
+        const float t2 = ((S[2] + S[1]) - 2.0f * S[0]) / (float)n;
+        const float v0 = V[0] / (float)n, v1 = V[1] / (float)n, v2 = V[2] / (float)n;
+        const float t3 = ((v0 + v1) + v2) / 3.0f;
+        const double t4 = (double)edges[b * 4 + q] / (double)n;  // int64 / int -> float64
+        const double Q = (double)((t1 + t2) - t3) - t4;
+        score[q] = Q;
+        if (q == 0 || Q > best) { best = Q; arg = q; }  // np.argmax: first maximum
+    }
+    if (trace) {
+        TraceRec &t = trace[b * kMaxLevels + level];
+        const Region k = blk[b];
+        t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
+        for (int q = 0; q < 4; ++q) t.score[q] = score[q];
+    }
+    blk[b] = regs[b * 4 + arg];
+}
+
+// get_brightest_pixel (six_stadigy.py:160-165): argmax of (r+g)+b over the leaf, first maximum in raster order.
+__global__ void __launch_bounds__(64) k_brightest(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                  const Region *__restrict__ blk, int H, int W, float *__restrict__ A)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const Region r = blk[b];
+    const int k = kind ? kind[b] : 0;
+    const uint8_t *img = in + (size_t)b * H * W * 3;
+    const int n = r.rows * r.cols;
+    float best = -1.0f;
+    int bi = 0x7fffffff;
+    for (int e = lane; e < n; e += 64) {
+        const uint8_t *p = img + ((size_t)(r.y0 + e / r.cols) * W + r.x0 + e % r.cols) * 3;
+        const float v = (px_val(p[0], false) + px_val(p[1], px_atten(k, 1))) + px_val(p[2], px_atten(k, 2));
+        if (v > best) { best = v; bi = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const uint8_t *p = img + ((size_t)(r.y0 + bi / r.cols) * W + r.x0 + bi % r.cols) * 3;
+        A[b * 3 + 0] = px_val(p[0], false);
+        A[b * 3 + 1] = px_val(p[1], px_atten(k, 1));
+        A[b * 3 + 2] = px_val(p[2], px_atten(k, 2));
+    }
+}
+
+int max_chunks(Shape s) { return cdiv((long long)((s.H + 1) / 2) * ((s.W + 1) / 2), kNpChunk); }
+
+LevelBufs carve_level(Carver &c, Shape s)
+{
+    LevelBufs L;
+    const size_t nreg = (size_t)s.B * 4;
+    L.blk = c.take<Region>(s.B);
+    L.regs = c.take<Region>(nreg);
+    L.csum = c.take<float>(nreg * max_chunks(s) * 3);
+    L.tot = c.take<float>(nreg * 3);
+    L.mean = c.take<float>(nreg * 3);
+    L.vtot = c.take<float>(nreg * 3);
+    L.edges = c.take<uint32_t>(nreg);
+    return L;
+}
+
+}  // namespace
+
+size_t airlight_ws_bytes(Shape s)
+{
+    Carver c(nullptr);
+    carve_level(c, s);
+    return c.total() + canny_ws_bytes(s);
+}
+
+int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const uint8_t *d_gray, Shape s,
+                    int min_size, float *d_A, void *d_trace, void *ws, hipStream_t st)
+{
+    (void)ctx;
+    Carver c(ws);
+    LevelBufs L = carve_level(c, s);
+    void *canny_ws = c.take<char>(canny_ws_bytes(s));
+    const int B = s.B, nreg = 4 * B;
+    hipLaunchKernelGGL(k_init_blocks, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, B, s.H, s.W);
+    UWIE_LAUNCH_CHECK();
+    if (d_trace) UWIE_HIP_CHECK(hipMemsetAsync(d_trace, 0, (size_t)B * kMaxLevels * sizeof(TraceRec), st));
+    const int maxChunks = max_chunks(s);
+    int rmax = s.H, cmax = s.W;  // largest block any image can hold at this level
+    for (int level = 0; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
+        const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
+        const int nch = cdiv((long long)qr * qc, kNpChunk);
+        hipLaunchKernelGGL(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
+        UWIE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
+                           s.W, maxChunks, L.csum);
+        UWIE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+                           maxChunks, L.tot, L.mean);
+        UWIE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
+                           s.W, maxChunks, L.csum);
+        UWIE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+                           maxChunks, L.vtot, L.mean);
+        UWIE_LAUNCH_CHECK();
+        int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st);
+        if (rc != UWIE_OK) return rc;
+        hipLaunchKernelGGL(k_q_select, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, L.tot, L.vtot, L.edges, B,
+                           level, (TraceRec *)d_trace);
+        UWIE_LAUNCH_CHECK();
+        rmax = qr;
+        cmax = qc;
+    }
+    hipLaunchKernelGGL(k_brightest, dim3(B), dim3(64), 0, st, d_in, d_kind, L.blk, s.H, s.W, d_A);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+}  // namespace uwie

@@ -1,0 +1,248 @@
+// cv2.Canny(gray, low, high) with aperture 3 and the L1 gradient norm (six_stadigy.py:150,
+// enhancement_strategies.py:181), evaluated on a list of rectangular REGIONS of the gray plane.  compute_Q
+// runs Canny on every quadrant of the quadtree block separately (each quadrant is its own image: Sobel
+// replicates ITS border and the magnitude outside it is 0), so a region here is one quadrant; the standalone
+// entry point uses one region per frame.
+//
+// Stages (all integer arithmetic, bit-exact by construction):
+//   k_canny_grad   3x3 Sobel with BORDER_REPLICATE at the region edge -> |dx|+|dy| and the NMS direction class
+//   k_canny_nms    non-maximum suppression with OpenCV's fixed-point tan(22.5 deg) -> map {weak, none, strong}
+//   k_canny_union  8-connected components of (weak | strong) pixels: lock-free union-find on pixel indices
+//                  (links always point to the smaller index; agent-scope atomics, so XCD placement is irrelevant)
+//   k_canny_flat   pointer jumping: every candidate points at its root
+//   k_canny_mark   roots that own a strong pixel are flagged
+//   k_canny_emit   a candidate is an edge iff its root is flagged (= hysteresis); per-region edge counts
+// Hysteresis is order independent (an edge pixel is a weak-or-strong pixel whose 8-connected component holds a
+// strong one), so the component formulation equals OpenCV's stack-based flood fill.
+#include "common.h"
+#include "devutil.h"
+
+namespace uwie {
+
+namespace {
+
+struct CannyBufs {
+    uint16_t *magdir;  // |dx|+|dy| (<= 2040) | dir << 12, per pixel of the frame
+    uint8_t *cmap;     // 0 weak, 1 none, 2 strong
+    int32_t *label;    // union-find parent (index inside the frame) or -1
+    uint8_t *flag;     // root owns a strong pixel
+};
+
+__device__ __forceinline__ bool region_px(const Region &r, int lp, int &y, int &x)
+{
+    if (lp >= r.rows * r.cols) return false;
+    y = r.y0 + lp / r.cols;
+    x = r.x0 + lp % r.cols;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_canny_grad(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
+                                                    int H, int W, uint16_t *__restrict__ magdir)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    const uint8_t *g = gray + (size_t)r.img * H * W;
+    const int ym = max(y - 1, r.y0), yp = min(y + 1, r.y0 + r.rows - 1);
+    const int xm = max(x - 1, r.x0), xp = min(x + 1, r.x0 + r.cols - 1);
+    const int a = g[(size_t)ym * W + xm], b = g[(size_t)ym * W + x], c = g[(size_t)ym * W + xp];
+    const int d = g[(size_t)y * W + xm], f = g[(size_t)y * W + xp];
+    const int p = g[(size_t)yp * W + xm], q = g[(size_t)yp * W + x], s = g[(size_t)yp * W + xp];
+    const int dx = (c - a) + 2 * (f - d) + (s - p);
+    const int dy = (p - a) + 2 * (q - b) + (s - c);
+    const int ax = abs(dx), ay = abs(dy) << 15;
+    const int tg22x = ax * 13573;  // (int)(tan(22.5deg) * 2^15 + 0.5)
+    int dir;
+    if (ay < tg22x) dir = 0;
+    else if (ay > tg22x + (ax << 16)) dir = 1;
+    else dir = ((dx ^ dy) < 0) ? 3 : 2;
+    magdir[(size_t)r.img * H * W + (size_t)y * W + x] = (uint16_t)((abs(dx) + abs(dy)) | (dir << 12));
+}
+
+__global__ void __launch_bounds__(256) k_canny_nms(const Region *__restrict__ regs, int H, int W, int low, int high,
+                                                   CannyBufs bufs)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    const size_t base = (size_t)r.img * H * W;
+    const uint16_t *md = bufs.magdir + base;
+    auto M = [&](int yy, int xx) -> int {
+        if (yy < r.y0 || yy >= r.y0 + r.rows || xx < r.x0 || xx >= r.x0 + r.cols) return 0;
+        return md[(size_t)yy * W + xx] & 0xfff;
+    };
+    const int v = md[(size_t)y * W + x];
+    const int m = v & 0xfff, dir = v >> 12;
+    bool keep = false;
+    if (m > low) {
+        if (dir == 0) keep = m > M(y, x - 1) && m >= M(y, x + 1);
+        else if (dir == 1) keep = m > M(y - 1, x) && m >= M(y + 1, x);
+        else if (dir == 2) keep = m > M(y - 1, x - 1) && m > M(y + 1, x + 1);
+        else keep = m > M(y - 1, x + 1) && m > M(y + 1, x - 1);
+    }
+    const int p = y * W + x;
+    bufs.cmap[base + p] = keep ? (m > high ? 2 : 0) : 1;
+    bufs.label[base + p] = keep ? p : -1;
+    bufs.flag[base + p] = 0;
+}
+
+__device__ __forceinline__ int ld_label(const int32_t *L, int i)
+{
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Root of i with path halving.  Parent links only ever decrease, so a stale read is still an ancestor.
+__device__ int uf_find(int32_t *L, int i)
+{
+    for (;;) {
+        const int p = ld_label(L, i);
+        if (p == i) return i;
+        const int gp = ld_label(L, p);
+        if (gp == p) return p;
+        atomicMin(L + i, gp);
+        i = gp;
+    }
+}
+
+__device__ void uf_union(int32_t *L, int a, int b)
+{
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicCAS(L + a, a, b);  // link the larger root under the smaller one
+        if (old == a) return;
+        a = old;  // somebody re-parented `a` first: continue from its new parent
+    }
+}
+
+__global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    const size_t base = (size_t)r.img * H * W;
+    const uint8_t *cm = bufs.cmap + base;
+    int32_t *L = bufs.label + base;
+    const int p = y * W + x;
+    if (cm[p] == 1) return;
+    const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
+    if (right && cm[p + 1] != 1) uf_union(L, p, p + 1);
+    if (down) {
+        if (left && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
+        if (cm[p + W] != 1) uf_union(L, p, p + W);
+        if (right && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_canny_flat(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    int32_t *L = bufs.label + (size_t)r.img * H * W;
+    const int p = y * W + x;
+    if (ld_label(L, p) < 0) return;
+    int root = p;
+    for (;;) {
+        const int q = ld_label(L, root);
+        if (q == root) break;
+        root = q;
+    }
+    if (root != p) atomicMin(L + p, root);
+}
+
+__global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    const size_t base = (size_t)r.img * H * W;
+    const int p = y * W + x;
+    if (bufs.cmap[base + p] != 2) return;
+    const int32_t *L = bufs.label + base;
+    int root = p;
+    while (L[root] != root) root = L[root];
+    bufs.flag[base + root] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
+                                                    uint32_t *__restrict__ count, uint8_t *__restrict__ edges)
+{
+    const Region r = regs[blockIdx.y];
+    int y, x;
+    bool edge = false;
+    if (region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) {
+        const size_t base = (size_t)r.img * H * W;
+        const int p = y * W + x;
+        const int32_t *L = bufs.label + base;
+        if (L[p] >= 0) {
+            int root = p;
+            while (L[root] != root) root = L[root];
+            edge = bufs.flag[base + root] != 0;
+        }
+        if (edges) edges[base + p] = edge ? 255 : 0;
+    }
+    if (count) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(edge));
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(count + blockIdx.y, n);
+    }
+}
+
+__global__ void k_full_regions(Region *regs, int B, int H, int W)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) regs[b] = Region{b, 0, 0, H, W};
+}
+
+CannyBufs carve_canny(Carver &c, Shape s)
+{
+    CannyBufs b;
+    const size_t n = (size_t)s.B * s.npx();
+    b.magdir = c.take<uint16_t>(n);
+    b.cmap = c.take<uint8_t>(n);
+    b.label = c.take<int32_t>(n);
+    b.flag = c.take<uint8_t>(n);
+    return b;
+}
+
+}  // namespace
+
+size_t canny_ws_bytes(Shape s)
+{
+    Carver c(nullptr);
+    carve_canny(c, s);
+    return c.total();
+}
+
+int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_full_regions, dim3(cdiv(s.B, 64)), dim3(64), 0, st, d_regions, s.B, s.H, s.W);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
+                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st)
+{
+    Carver c(ws);
+    CannyBufs bufs = carve_canny(c, s);
+    const dim3 grid(cdiv((long long)max_rows * max_cols, 256), nreg), block(256);
+    if (d_count) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
+    hipLaunchKernelGGL(k_canny_grad, grid, block, 0, st, d_gray, d_regions, s.H, s.W, bufs.magdir);
+    UWIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_canny_nms, grid, block, 0, st, d_regions, s.H, s.W, low, high, bufs);
+    UWIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_canny_union, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_canny_flat, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_canny_mark, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_canny_emit, grid, block, 0, st, d_regions, s.H, s.W, bufs, d_count, d_edges);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+}  // namespace uwie

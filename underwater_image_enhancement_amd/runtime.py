@@ -1,0 +1,241 @@
+"""Device runtime: one libuwie context per GPU, torch tensors as the HBM containers.
+
+PyTorch is plumbing here (device memory, streams); every enhancement operation is a
+hand-written HIP kernel reached through the C ABI in include/uwie.h.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import UwieParams, check
+
+_TRACE_DTYPE = np.dtype([("y0", "<i4"), ("x0", "<i4"), ("rows", "<i4"), ("cols", "<i4"), ("score", "<f8", (4,))])
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Device:
+    """A libuwie context bound to one MI355X.  Not thread-safe; use one per host thread / stream."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.UwieError("no ROCm device visible: the enhancement path has no CPU fallback")
+        self.lib = _lib.load()
+        self.index = int(device)
+        self.torch_device = torch.device("cuda", self.index)
+        torch.cuda.set_device(self.index)
+        handle = ctypes.c_void_p()
+        check(self.lib.uwie_create(self.index, ctypes.byref(handle)))
+        self._ctx = handle
+        self._workspace = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            torch.cuda.synchronize(self.index)
+            self.lib.uwie_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.index).cuda_stream)
+
+    def workspace(self, nbytes: int):
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=self.torch_device)
+        return self._workspace
+
+    def params(self, surface: int, strategy: int, **overrides) -> UwieParams:
+        p = UwieParams()
+        check(self.lib.uwie_params_init(ctypes.byref(p), surface, strategy))
+        for key, value in overrides.items():
+            if not hasattr(p, key):
+                raise KeyError(key)
+            setattr(p, key, value)
+        return p
+
+    def workspace_for(self, B, H, W, p: UwieParams | None = None):
+        n = self.lib.uwie_workspace_bytes(B, H, W, ctypes.byref(p) if p is not None else None)
+        if n == 0:
+            raise _lib.UwieError("batch/H/W out of range")
+        return self.workspace(n)
+
+    def tensor(self, array, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(array))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.torch_device)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.torch_device)
+
+    @staticmethod
+    def _bhw(img):
+        assert img.dim() == 4 and img.shape[-1] == 3 and img.is_contiguous(), "expected contiguous [B,H,W,3]"
+        return int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+
+    # ------------------------------------------------------------------ whole pipeline
+    def enhance_u8(self, frames, p: UwieParams, want_float: bool = False):
+        """frames: uint8 cuda tensor [B,H,W,3] -> (uint8 [B,H,W,3], float32 [B,H,W,3] or None)."""
+        B, H, W = self._bhw(frames)
+        assert frames.dtype == torch.uint8
+        ws = self.workspace_for(B, H, W, p)
+        out = self.empty((B, H, W, 3), torch.uint8)
+        outf = self.empty((B, H, W, 3), torch.float32) if want_float else None
+        check(self.lib.uwie_enhance_u8(self._ctx, _ptr(frames), _ptr(out), _ptr(outf), B, H, W, ctypes.byref(p),
+                                       _ptr(ws), ws.numel(), self.stream()))
+        return out, outf
+
+    # ------------------------------------------------------------------ stages
+    def cast_classify(self, frames):
+        B, H, W = self._bhw(frames)
+        ws = self.workspace_for(B, H, W)
+        kind = self.empty((B,), torch.int32)
+        mean = self.empty((B, 3), torch.float32)
+        check(self.lib.uwie_cast_classify(self._ctx, _ptr(frames), B, H, W, _ptr(kind), _ptr(mean), _ptr(ws),
+                                          ws.numel(), self.stream()))
+        return kind, mean
+
+    def normalise_correct(self, frames, kind=None):
+        B, H, W = self._bhw(frames)
+        out = self.empty((B, H, W, 3), torch.float32)
+        check(self.lib.uwie_normalise_correct(self._ctx, _ptr(frames), _ptr(kind), _ptr(out), B, H, W, self.stream()))
+        return out
+
+    def atmospheric_light(self, frames, kind=None, p: UwieParams | None = None, trace: bool = False):
+        B, H, W = self._bhw(frames)
+        p = p or self.params(_lib.SURFACE_SIX, 2)
+        ws = self.workspace_for(B, H, W, p)
+        A = self.empty((B, 3), torch.float32)
+        tr = torch.zeros((B, 32, _TRACE_DTYPE.itemsize), dtype=torch.uint8, device=self.torch_device) if trace else None
+        check(self.lib.uwie_atmospheric_light(self._ctx, _ptr(frames), _ptr(kind), B, H, W, ctypes.byref(p), _ptr(A),
+                                              _ptr(tr), _ptr(ws), ws.numel(), self.stream()))
+        if trace:
+            return A, tr.cpu().numpy().view(_TRACE_DTYPE).reshape(B, 32)
+        return A
+
+    def transmission_init(self, frames, A, kind=None, p: UwieParams | None = None):
+        B, H, W = self._bhw(frames)
+        p = p or self.params(_lib.SURFACE_SIX, 2)
+        t0 = self.empty((B, H, W), torch.float32)
+        gray = self.empty((B, H, W), torch.uint8)
+        check(self.lib.uwie_transmission_init(self._ctx, _ptr(frames), _ptr(kind), _ptr(A), B, H, W, ctypes.byref(p),
+                                              _ptr(t0), _ptr(gray), self.stream()))
+        return t0, gray
+
+    def box_filter_f64(self, planes, ksize):
+        B, H, W = (int(v) for v in planes.shape)
+        assert planes.dtype == torch.float64 and planes.is_contiguous()
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(planes)
+        check(self.lib.uwie_box_filter_f64(self._ctx, _ptr(planes), _ptr(out), B, H, W, int(ksize), _ptr(ws), ws.numel(),
+                                           self.stream()))
+        return out
+
+    def guided_filter(self, gray, t0, ksize, eps):
+        B, H, W = (int(v) for v in gray.shape)
+        ws = self.workspace_for(B, H, W)
+        t = self.empty((B, H, W), torch.float64)
+        check(self.lib.uwie_guided_filter(self._ctx, _ptr(gray), _ptr(t0), B, H, W, int(ksize), float(eps), _ptr(t),
+                                          _ptr(ws), ws.numel(), self.stream()))
+        return t
+
+    def restore(self, frames, A, t, kind=None):
+        B, H, W = self._bhw(frames)
+        out = self.empty((B, H, W, 3), torch.float32)
+        check(self.lib.uwie_restore(self._ctx, _ptr(frames), _ptr(kind), _ptr(A), _ptr(t), B, H, W, _ptr(out),
+                                    self.stream()))
+        return out
+
+    def percentiles_f32(self, img, q_percent):
+        B, H, W = self._bhw(img)
+        assert img.dtype == torch.float32
+        q = (ctypes.c_double * len(q_percent))(*[float(v) for v in q_percent])
+        ws = self.workspace_for(B, H, W)
+        out = self.empty((B, 3, len(q_percent)), torch.float32)
+        check(self.lib.uwie_percentiles_f32(self._ctx, _ptr(img), B, H, W, q, len(q_percent), _ptr(out), _ptr(ws),
+                                            ws.numel(), self.stream()))
+        return out
+
+    def stretch_f32(self, img, lo, hi):
+        B, H, W = self._bhw(img)
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(img)
+        check(self.lib.uwie_stretch_f32(self._ctx, _ptr(img), _ptr(out), B, H, W, float(lo), float(hi), _ptr(ws),
+                                        ws.numel(), self.stream()))
+        return out
+
+    def gamma_f32(self, img, g, mode=1):
+        out = torch.empty_like(img)
+        check(self.lib.uwie_gamma_f32(self._ctx, _ptr(img), _ptr(out), img.numel(), float(g), int(mode), self.stream()))
+        return out
+
+    def clahe_f32(self, img, clip, tiles=(8, 8)):
+        B, H, W = self._bhw(img)
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(img)
+        check(self.lib.uwie_clahe_f32(self._ctx, _ptr(img), _ptr(out), B, H, W, float(clip), int(tiles[0]),
+                                      int(tiles[1]), _ptr(ws), ws.numel(), self.stream()))
+        return out
+
+    def rgb2gray_u8(self, rgb, gray_shift=15):
+        out = self.empty(rgb.shape[:-1], torch.uint8)
+        check(self.lib.uwie_rgb2gray_u8(self._ctx, _ptr(rgb), _ptr(out), out.numel(), int(gray_shift), self.stream()))
+        return out
+
+    def rgb2lab_u8(self, rgb):
+        out = torch.empty_like(rgb)
+        check(self.lib.uwie_rgb2lab_u8(self._ctx, _ptr(rgb), _ptr(out), rgb.numel() // 3, self.stream()))
+        return out
+
+    def lab2rgb_u8(self, lab):
+        out = torch.empty_like(lab)
+        check(self.lib.uwie_lab2rgb_u8(self._ctx, _ptr(lab), _ptr(out), lab.numel() // 3, self.stream()))
+        return out
+
+    def clahe_u8(self, planes, clip, tiles=(8, 8)):
+        B, H, W = (int(v) for v in planes.shape)
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(planes)
+        check(self.lib.uwie_clahe_u8(self._ctx, _ptr(planes), _ptr(out), B, H, W, float(clip), int(tiles[0]),
+                                     int(tiles[1]), _ptr(ws), ws.numel(), self.stream()))
+        return out
+
+    def canny_u8(self, gray, low=50, high=150):
+        B, H, W = (int(v) for v in gray.shape)
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(gray)
+        check(self.lib.uwie_canny_u8(self._ctx, _ptr(gray), _ptr(out), B, H, W, int(low), int(high), _ptr(ws),
+                                     ws.numel(), self.stream()))
+        return out
+
+    def equalize_hist_u8(self, planes):
+        B, H, W = (int(v) for v in planes.shape)
+        ws = self.workspace_for(B, H, W)
+        out = torch.empty_like(planes)
+        check(self.lib.uwie_equalize_hist_u8(self._ctx, _ptr(planes), _ptr(out), B, H, W, _ptr(ws), ws.numel(),
+                                             self.stream()))
+        return out
+
+
+_devices: dict[int, Device] = {}
+
+
+def get_device(index: int | None = None) -> Device:
+    if index is None:
+        index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if index not in _devices:
+        _devices[index] = Device(index)
+    return _devices[index]
