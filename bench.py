@@ -1,0 +1,188 @@
+"""Throughput of the canonical enhance() on synthetic frames resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One step = one pass of uwie_enhance_u8 (strategy 2, cast correction on: the canonical path of SURVEY.md section 8)
+over one batch of synthetic "underwater" uint8 frames per GPU.  Default workload: BASELINE.json configs[2], the
+configuration the target metric is quoted on -- 4K (3840x2160) RGB, batch 64 per GPU.  Batches shard across ranks
+with no data-path collective (frames are independent), so scaling is weak; the only collectives are the barriers
+and the MAX of the elapsed time.  Prints ONE JSON line on rank 0.
+
+`roofline`    : the dominant kernel of the timed region (HIP events on the launch stream, recorded inside libuwie),
+                its algorithmic bytes (table below) over its measured time, against 8 TB/s HBM.
+`cpu_baseline`: the CPU oracle (oracle/uwie_oracle.py: NumPy + C restatement, single thread, kind "port") timed on
+                rank 0 at N=1 on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PIPELINE_BYTES_PER_PX = 19.0  # five dependent streaming phases over the u8 frame + 3 B written
+
+# Algorithmic bytes per frame pixel moved by ALL launches of a kernel in one step (per launch = this / launches).
+# Quadtree kernels run once per level on a block a quarter the size of the previous one: sum = 4/3.
+Q = 4.0 / 3.0
+KERNEL_BYTES_PER_PX = {
+    "k_chunk_hist": 3, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
+    "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_grad": (1 + 2) * Q,
+    "k_canny_nms": (2 + 1 + 4 + 1) * Q, "k_canny_union": (1 + 4) * Q, "k_canny_flat": (4 + 4) * Q,
+    "k_canny_mark": (1 + 4) * Q, "k_canny_emit": 4 * Q,
+    "k_trans_init": 3 + 4, "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
+    "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
+    "k_sel_hist": 3 * 12, "k_stretch_apply": 12 + 12, "k_quant_rgb2lab": 12 + 3, "k_clahe_lut": 1,
+    "k_clahe_apply": 1 + 1, "k_lab2rgb_f32": 3 + 12, "k_gamma": 12 + 12, "k_quantise": 12 + 3,
+    "k_normalise_correct": 3 + 12,
+}
+
+
+def synth_underwater(batch, H, W, device, seed):
+    """Seeded synthetic frames: smooth field x greenish/bluish channel gains + noise."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    yy = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    out = torch.empty((batch, H, W, 3), dtype=torch.uint8, device=device)
+    for b in range(batch):
+        ph = torch.rand(8, generator=g, device=device) * 6.283
+        field = 0.55 + 0.25 * (torch.sin(xx / (W / 9.0) + ph[0]) * torch.cos(yy / (H / 7.0) + ph[1])
+                               + 0.5 * torch.sin((xx + 2 * yy) / (W / 5.0) + ph[2])
+                               + 0.5 * torch.cos((2 * xx - yy) / (W / 13.0) + ph[3])) / 2.0
+        gains = (0.45, 0.85, 0.80) if b % 2 == 0 else (0.45, 0.75, 0.90)
+        for c in range(3):
+            ch = field * gains[c] + torch.randn((H, W), generator=g, device=device) * 0.02
+            out[b, :, :, c] = torch.clamp(torch.floor(ch * 255.0), 0, 255).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(H, W, seed, budget_s=25.0):
+    """Time the CPU oracle on a bounded sample: whole frames of the same workload, at least one, until ~budget."""
+    import numpy as np
+    import torch
+
+    from oracle import uwie_oracle as orc
+
+    frames = synth_underwater(2, H, W, torch.device("cpu"), seed).numpy()
+    orc.enhance_u8(np.ascontiguousarray(frames[0, : H // 8, : W // 8]), 2)  # warm-up (library load, tables)
+    done, t0 = 0, time.perf_counter()
+    while done < len(frames):
+        orc.enhance_u8(frames[done], 2)
+        done += 1
+        if time.perf_counter() - t0 > budget_s * 0.5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(done * H * W / 1e6 / dt, 3), "unit": "megapixels/sec", "cores": 1, "kind": "port",
+            "sample": f"{done} frame(s) of {W}x{H} through oracle.enhance_u8 (NumPy + C restatement, 1 thread), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--strategy", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import underwater_image_enhancement_amd as uw
+    from underwater_image_enhancement_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    dev = uw.get_device(local)
+    H, W, B = args.height, args.width, args.batch
+    frames = synth_underwater(B, H, W, dev.torch_device, seed=1000 * 2 + rank)
+    p = dev.params(_lib.SURFACE_SIX, args.strategy)
+    ws = dev.workspace_for(B, H, W, p)
+    out = dev.empty((B, H, W, 3), torch.uint8)
+
+    import ctypes
+
+    def step():
+        _lib.check(dev.lib.uwie_enhance_u8(dev._ctx, ctypes.c_void_p(frames.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                           None, B, H, W, ctypes.byref(p), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                           dev.stream()))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rows = dev.profile_rows()
+    dev.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev.torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    if rank == 0:
+        px_step = B * H * W
+        value = world * px_step * args.steps / elapsed / 1e6
+        name, (ms, calls) = max(rows.items(), key=lambda kv: kv[1][0])
+        per_launch_ms = ms / calls
+        launches_per_step = calls / args.steps
+        bytes_launch = KERNEL_BYTES_PER_PX.get(name, 0) * px_step / launches_per_step
+        achieved = bytes_launch / (per_launch_ms * 1e-3) / 1e9
+        kernel_ms = sum(v[0] for v in rows.values()) / args.steps
+        result = {
+            "metric": "megapixels/sec enhanced", "value": round(value, 2), "unit": "megapixels/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} RGB u8, batch={B} per GPU, strategy{args.strategy} + cast correction "
+                                   "(canonical enhance, BASELINE.json configs[2])",
+                       "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": name,
+                         "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "kernel_share_of_step": round(ms / args.steps / (elapsed / args.steps * 1e3), 4),
+                         "pipeline_achieved": round(PIPELINE_BYTES_PER_PX * px_step * args.steps / elapsed / 1e9, 2),
+                         "pipeline_frac": round(PIPELINE_BYTES_PER_PX * px_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                         "sum_kernel_ms_per_step": round(kernel_ms, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(H, W, seed=2000)
+        if os.environ.get("UWIE_BENCH_KERNELS"):
+            top = sorted(rows.items(), key=lambda kv: -kv[1][0])
+            print("# per-kernel ms/step: " + ", ".join(f"{k}={v[0] / args.steps:.3f}({v[1] // args.steps})" for k, v in top),
+                  file=sys.stderr)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,14 @@ const char *uwie_version(void);
 int uwie_create(int device, uwie_ctx **out_ctx);
 void uwie_destroy(uwie_ctx *ctx);
 
+/* Per-kernel timing for benchmarks (no reference counterpart; the reference only has a per-image wall clock,
+ * S6:393-500).  enable(1) starts recording one HIP-event pair per kernel launch on the launch stream;
+ * collect() synchronises the device, folds the intervals by kernel name and returns the number of rows
+ * (negative on error); row(i) reads one row.  Recording is per host thread. */
+int uwie_profile_enable(uwie_ctx *ctx, int on);
+int uwie_profile_collect(uwie_ctx *ctx);
+int uwie_profile_row(uwie_ctx *ctx, int i, const char **name, double *total_ms, int *calls);
+
 /* Fill `p` with the reference defaults for (surface, strategy). */
 int uwie_params_init(uwie_params *p, int surface, int strategy);
 

@@ -143,7 +143,7 @@ def test_equalize_hist_u8(dev, orc):
 def test_canny_u8(dev, orc):
     rng = np.random.default_rng(7)
     yy, xx = np.mgrid[0:90, 0:120]
-    smooth = (127 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0)).astype(np.uint8)
+    smooth = (127 + 120 * np.sin(xx / 4.0) * np.cos(yy / 5.0)).astype(np.uint8)
     blobs = np.zeros((90, 120), np.uint8)
     blobs[20:60, 30:80] = 180
     blobs[35:50, 50:110] = 90
@@ -239,8 +239,12 @@ def test_gamma_within_one_ulp_of_reference(dev, golden, tag):
         got = dev.gamma_f32(dev.tensor(img[None]), g, 1)[0].cpu().numpy()
         want = golden[f"{tag}/s6_gamma_{g}"]
         ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-        assert ulp.max() <= 1, f"gamma {g}: {ulp.max()} ulp"  # tolerance: 1 float32 ulp (device pow vs libm powf)
-        assert (ulp != 0).mean() < 1e-3
+        # Tolerance: 1 float32 ulp.  NumPy's float32 power is a SIMD routine that is itself only faithfully
+        # rounded (and CPU-dispatch dependent), so bit equality with it is not defined across machines; the device
+        # value is the correctly rounded one, which is checked against a float64 evaluation below.
+        assert ulp.max() <= 1, f"gamma {g}: {ulp.max()} ulp"
+        exact = np.power(img.astype(np.float64), np.float64(np.float32(g))).astype(np.float32)
+        assert (got != exact).mean() < 1e-5
         # after the output quantisation (x*255 -> u8, six_stadigy.py:430) the results are identical or 1 LSB apart
         q = np.abs((got * 255).astype(np.uint8).astype(int) - (want * 255).astype(np.uint8).astype(int))
         assert q.max() <= 1

@@ -56,6 +56,9 @@ SIGNATURES = {
     "uwie_version": [],
     "uwie_create": [_I, ctypes.POINTER(_VP)],
     "uwie_destroy": [_VP],
+    "uwie_profile_enable": [_VP, _I],
+    "uwie_profile_collect": [_VP],
+    "uwie_profile_row": [_VP, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_D), ctypes.POINTER(_I)],
     "uwie_params_init": [_PP, _I, _I],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
     "uwie_enhance_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],

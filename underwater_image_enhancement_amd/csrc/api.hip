@@ -178,6 +178,7 @@ int uwie_create(int device, uwie_ctx **out_ctx)
     UWIE_REQUIRE(device >= 0 && device < count, "device index out of range");
     UWIE_HIP_CHECK(hipSetDevice(device));
     uwie_ctx *ctx = new uwie_ctx();
+    ctx->prof = prof_create();
     ctx->device = device;
     LabTables *lab = new LabTables();
     CastTables *cast = new CastTables();
@@ -203,7 +204,32 @@ void uwie_destroy(uwie_ctx *ctx)
     if (!ctx) return;
     if (ctx->d_lab) (void)hipFree(ctx->d_lab);
     if (ctx->d_cast) (void)hipFree(ctx->d_cast);
+    prof_bind(nullptr);
+    prof_destroy(ctx->prof);
     delete ctx;
+}
+
+int uwie_profile_enable(uwie_ctx *ctx, int on)
+{
+    UWIE_REQUIRE(ctx != nullptr, "profile_enable: NULL context");
+    prof_enable(ctx->prof, on != 0);
+    prof_bind(on ? ctx->prof : nullptr);
+    return UWIE_OK;
+}
+
+int uwie_profile_collect(uwie_ctx *ctx)
+{
+    if (!ctx) {
+        set_error("profile_collect: NULL context");
+        return UWIE_E_INVALID;
+    }
+    return prof_collect(ctx->prof);
+}
+
+int uwie_profile_row(uwie_ctx *ctx, int i, const char **name, double *total_ms, int *calls)
+{
+    UWIE_REQUIRE(ctx && name && total_ms && calls, "profile_row: NULL pointer");
+    return prof_row(ctx->prof, i, name, total_ms, calls);
 }
 
 int uwie_params_init(uwie_params *p, int surface, int strategy)

@@ -49,12 +49,41 @@ struct CastTables {                         // rounding tables for the sequentia
 void build_lab_tables(LabTables *t);
 void build_cast_tables(CastTables *t);
 
+// ---------------------------------------------------------------- optional per-kernel timing (prof.hip)
+struct Profiler;
+Profiler *prof_create();
+void prof_destroy(Profiler *p);
+void prof_enable(Profiler *p, bool on);
+void prof_bind(Profiler *p);  // makes p the recorder of this host thread (nullptr / disabled = no recording)
+int prof_collect(Profiler *p);
+int prof_row(Profiler *p, int i, const char **name, double *ms, int *calls);
+class ProfScope {  // records a start event now and a stop event when it goes out of scope
+public:
+    ProfScope(const char *name, hipStream_t st);
+    ~ProfScope();
+    ProfScope(const ProfScope &) = delete;
+
+private:
+    int rec_;
+    hipStream_t st_;
+};
+#define UWIE_PROF_CAT2(a, b) a##b
+#define UWIE_PROF_CAT(a, b) UWIE_PROF_CAT2(a, b)
+#define UWIE_PROF(name, st) ::uwie::ProfScope UWIE_PROF_CAT(_uwie_prof_, __LINE__)(name, st)
+// every kernel launch goes through this: named timing scope + launch
+#define UWIE_LAUNCH(kernel, grid, block, lds, st, ...)                      \
+    do {                                                                    \
+        UWIE_PROF(#kernel, st);                                             \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);      \
+    } while (0)
+
 }  // namespace uwie
 
 struct uwie_ctx {
     int device;
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;
+    uwie::Profiler *prof;
 };
 
 namespace uwie {

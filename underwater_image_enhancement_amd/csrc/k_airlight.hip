@@ -350,7 +350,7 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
     LevelBufs L = carve_level(c, s);
     void *canny_ws = c.take<char>(canny_ws_bytes(s));
     const int B = s.B, nreg = 4 * B;
-    hipLaunchKernelGGL(k_init_blocks, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, B, s.H, s.W);
+    UWIE_LAUNCH(k_init_blocks, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, B, s.H, s.W);
     UWIE_LAUNCH_CHECK();
     if (d_trace) UWIE_HIP_CHECK(hipMemsetAsync(d_trace, 0, (size_t)B * kMaxLevels * sizeof(TraceRec), st));
     const int maxChunks = max_chunks(s);
@@ -358,29 +358,29 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
     for (int level = 0; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
         const int nch = cdiv((long long)qr * qc, kNpChunk);
-        hipLaunchKernelGGL(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
+        UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
         UWIE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
+        UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum);
         UWIE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+        UWIE_LAUNCH(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
                            maxChunks, L.tot, L.mean);
         UWIE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
+        UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum);
         UWIE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+        UWIE_LAUNCH(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
                            maxChunks, L.vtot, L.mean);
         UWIE_LAUNCH_CHECK();
         int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st);
         if (rc != UWIE_OK) return rc;
-        hipLaunchKernelGGL(k_q_select, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, L.tot, L.vtot, L.edges, B,
+        UWIE_LAUNCH(k_q_select, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, L.tot, L.vtot, L.edges, B,
                            level, (TraceRec *)d_trace);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
         cmax = qc;
     }
-    hipLaunchKernelGGL(k_brightest, dim3(B), dim3(64), 0, st, d_in, d_kind, L.blk, s.H, s.W, d_A);
+    UWIE_LAUNCH(k_brightest, dim3(B), dim3(64), 0, st, d_in, d_kind, L.blk, s.H, s.W, d_A);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

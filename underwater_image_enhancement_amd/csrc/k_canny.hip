@@ -218,7 +218,7 @@ size_t canny_ws_bytes(Shape s)
 
 int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_full_regions, dim3(cdiv(s.B, 64)), dim3(64), 0, st, d_regions, s.B, s.H, s.W);
+    UWIE_LAUNCH(k_full_regions, dim3(cdiv(s.B, 64)), dim3(64), 0, st, d_regions, s.B, s.H, s.W);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -230,17 +230,17 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     CannyBufs bufs = carve_canny(c, s);
     const dim3 grid(cdiv((long long)max_rows * max_cols, 256), nreg), block(256);
     if (d_count) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
-    hipLaunchKernelGGL(k_canny_grad, grid, block, 0, st, d_gray, d_regions, s.H, s.W, bufs.magdir);
+    UWIE_LAUNCH(k_canny_grad, grid, block, 0, st, d_gray, d_regions, s.H, s.W, bufs.magdir);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_canny_nms, grid, block, 0, st, d_regions, s.H, s.W, low, high, bufs);
+    UWIE_LAUNCH(k_canny_nms, grid, block, 0, st, d_regions, s.H, s.W, low, high, bufs);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_canny_union, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH(k_canny_union, grid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_canny_flat, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH(k_canny_flat, grid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_canny_mark, grid, block, 0, st, d_regions, s.H, s.W, bufs);
+    UWIE_LAUNCH(k_canny_mark, grid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_canny_emit, grid, block, 0, st, d_regions, s.H, s.W, bufs, d_count, d_edges);
+    UWIE_LAUNCH(k_canny_emit, grid, block, 0, st, d_regions, s.H, s.W, bufs, d_count, d_edges);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

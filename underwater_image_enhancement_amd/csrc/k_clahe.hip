@@ -249,19 +249,19 @@ ClaheGeom make_geom(Shape s, double clip, int tx, int ty)
 
 int launch_rgb2gray_u8(const uint8_t *d_rgb, uint8_t *d_gray, size_t n, int shift, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rgb2gray, dim3(grid_for(n)), dim3(256), 0, st, d_rgb, d_gray, n, shift);
+    UWIE_LAUNCH(k_rgb2gray, dim3(grid_for(n)), dim3(256), 0, st, d_rgb, d_gray, n, shift);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
 int launch_rgb2lab_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_lab, size_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rgb2lab, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_rgb, d_lab, n);
+    UWIE_LAUNCH(k_rgb2lab, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_rgb, d_lab, n);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
 int launch_lab2rgb_u8(uwie_ctx *ctx, const uint8_t *d_lab, uint8_t *d_rgb, size_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_lab2rgb, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_lab, d_rgb, n);
+    UWIE_LAUNCH(k_lab2rgb, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_lab, d_rgb, n);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -279,9 +279,9 @@ static int clahe_plane(const uint8_t *src, int ps, uint8_t *dst, int pd, Shape s
 {
     UWIE_REQUIRE(tx >= 1 && ty >= 1 && tx * ty <= 4096, "clahe: bad tile grid");
     const ClaheGeom g = make_geom(s, clip, tx, ty);
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tx * ty, s.B), dim3(256), 0, st, src, ps, g, lut);
+    UWIE_LAUNCH(k_clahe_lut, dim3(tx * ty, s.B), dim3(256), 0, st, src, ps, g, lut);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_clahe_apply, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, src, ps, lut, g, dst, pd);
+    UWIE_LAUNCH(k_clahe_apply, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, src, ps, lut, g, dst, pd);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -302,11 +302,11 @@ int launch_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, Shape s, d
     uint8_t *lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
     uint8_t *lab = c.take<uint8_t>((size_t)s.B * s.npx() * 3);
     const size_t n = (size_t)s.B * s.npx();
-    hipLaunchKernelGGL(k_quant_rgb2lab, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_img, lab, n);
+    UWIE_LAUNCH(k_quant_rgb2lab, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, d_img, lab, n);
     UWIE_LAUNCH_CHECK();
     int rc = clahe_plane(lab, 3, lab, 3, s, clip, tx, ty, lut, st);  // in place on the L byte of every pixel
     if (rc != UWIE_OK) return rc;
-    hipLaunchKernelGGL(k_lab2rgb_f32, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, lab, d_out, n);
+    UWIE_LAUNCH(k_lab2rgb_f32, dim3(grid_for(n)), dim3(256), 0, st, ctx->d_lab, lab, d_out, n);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -315,9 +315,9 @@ int launch_equalize_hist_u8(const uint8_t *d_plane, uint8_t *d_out, Shape s, voi
 {
     Carver c(ws);
     uint8_t *lut = c.take<uint8_t>((size_t)s.B * 256);
-    hipLaunchKernelGGL(k_eqhist_lut, dim3(s.B), dim3(256), 0, st, d_plane, (int)s.npx(), lut);
+    UWIE_LAUNCH(k_eqhist_lut, dim3(s.B), dim3(256), 0, st, d_plane, (int)s.npx(), lut);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_apply_lut_u8, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_plane, lut, d_out, (int)s.npx());
+    UWIE_LAUNCH(k_apply_lut_u8, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_plane, lut, d_out, (int)s.npx());
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

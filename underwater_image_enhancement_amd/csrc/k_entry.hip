@@ -164,11 +164,11 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     const int nchunk = cdiv(npx, kChunkPx);
     uint32_t *hist = c.take<uint32_t>((size_t)s.B * nchunk * 768);
     float *sums = c.take<float>((size_t)s.B * 3);
-    hipLaunchKernelGGL(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, hist, npx, nchunk);
+    UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, hist, npx, nchunk);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, hist, ctx->d_cast, npx, nchunk, sums);
+    UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, hist, ctx->d_cast, npx, nchunk, sums);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cast_decide, dim3(cdiv(s.B, 64)), dim3(64), 0, st, sums, s.B, npx, d_kind, d_mean);
+    UWIE_LAUNCH(k_cast_decide, dim3(cdiv(s.B, 64)), dim3(64), 0, st, sums, s.B, npx, d_kind, d_mean);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -181,7 +181,7 @@ __global__ void k_set_kind(int32_t *kind, int B, int v)
 
 int launch_set_kind(int32_t *d_kind, int B, int kind, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_set_kind, dim3(cdiv(B, 64)), dim3(64), 0, st, d_kind, B, kind);
+    UWIE_LAUNCH(k_set_kind, dim3(cdiv(B, 64)), dim3(64), 0, st, d_kind, B, kind);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_normalise_correct(const uint8_t *__rest
 int launch_normalise_correct(const uint8_t *d_in, const int32_t *d_kind, float *d_out, Shape s, hipStream_t st)
 {
     const int blocks = grid_for(s.npx() * 3, 4096);
-    hipLaunchKernelGGL(k_normalise_correct, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_out, (int)s.npx());
+    UWIE_LAUNCH(k_normalise_correct, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_out, (int)s.npx());
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -225,7 +225,7 @@ int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gra
                       hipStream_t st)
 {
     const int blocks = grid_for(s.npx(), 4096);
-    hipLaunchKernelGGL(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_gray, (int)s.npx(), gray_shift);
+    UWIE_LAUNCH(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_gray, (int)s.npx(), gray_shift);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -174,7 +174,7 @@ int launch_trans_init(const uint8_t *d_in, const int32_t *d_kind, const float *d
                       int pre_clip, float *d_t0, hipStream_t st)
 {
     const int blocks = grid_for(s.npx(), 4096);
-    hipLaunchKernelGGL(k_trans_init, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_A, (int)s.npx(), omega,
+    UWIE_LAUNCH(k_trans_init, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_A, (int)s.npx(), omega,
                        norm_eps, pre_clip, d_t0);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
@@ -192,10 +192,10 @@ int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, vo
     Carver c(ws);
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n);
-    hipLaunchKernelGGL(k_box_rows<SrcPlanes1>, dim3(cdiv((long long)s.B * s.H, 64)), dim3(64), 0, st,
+    UWIE_LAUNCH(k_box_rows<SrcPlanes1>, dim3(cdiv((long long)s.B * s.H, 64)), dim3(64), 0, st,
                        SrcPlanes1{d_src, s.H, s.W}, rs, n, s.B, k);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_box_cols<EpiStore1>, dim3(cdiv((long long)s.B * s.W, 64)), dim3(64), 0, st, rs, n,
+    UWIE_LAUNCH(k_box_cols<EpiStore1>, dim3(cdiv((long long)s.B * s.W, 64)), dim3(64), 0, st, rs, n,
                        EpiStore1{d_dst}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
@@ -216,13 +216,13 @@ int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, doub
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
     const dim3 grows(cdiv((long long)s.B * s.H, 64)), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
-    hipLaunchKernelGGL(k_box_rows<SrcGuide>, grows, blk, 0, st, SrcGuide{d_gray, d_t0, s.H, s.W}, rs, n, s.B, k);
+    UWIE_LAUNCH(k_box_rows<SrcGuide>, grows, blk, 0, st, SrcGuide{d_gray, d_t0, s.H, s.W}, rs, n, s.B, k);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
+    UWIE_LAUNCH(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_box_rows<SrcPlanes2>, grows, blk, 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, s.B, k);
+    UWIE_LAUNCH(k_box_rows<SrcPlanes2>, grows, blk, 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, s.B, k);
     UWIE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
+    UWIE_LAUNCH(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

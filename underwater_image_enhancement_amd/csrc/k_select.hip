@@ -210,21 +210,21 @@ int launch_percentiles_f32(const float *d_vals, int planar, Shape s, const doubl
     ranks.n = 2 * nq;
     fr.n = nq;
     for (int j = 0; j < nq; ++j) percentile_indices(n, q_percent[j], &ranks.r[2 * j], &ranks.r[2 * j + 1], &fr.t[j]);
-    hipLaunchKernelGGL(k_sel_init, dim3(cdiv(nbc, 64)), dim3(64), 0, st, state, nbc, ranks);
+    UWIE_LAUNCH(k_sel_init, dim3(cdiv(nbc, 64)), dim3(64), 0, st, state, nbc, ranks);
     UWIE_LAUNCH_CHECK();
     const int shifts[3] = {21, 10, 0}, bitsv[3] = {11, 11, 10};
     const int blocks = grid_for((size_t)n / 64 + 1, 128);
     for (int p = 0; p < 3; ++p) {
         UWIE_HIP_CHECK(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
         const size_t lds = (size_t)(p == 0 ? 1 : kMaxRanks) * (1u << bitsv[p]) * sizeof(uint32_t);
-        hipLaunchKernelGGL(k_sel_hist, dim3(blocks, nbc), dim3(256), lds, st, d_vals, (size_t)n * 3,
+        UWIE_LAUNCH(k_sel_hist, dim3(blocks, nbc), dim3(256), lds, st, d_vals, (size_t)n * 3,
                            planar ? (size_t)n : (size_t)1, planar ? 1 : 3, (int)n, state, shifts[p], bitsv[p],
                            p == 0 ? 1 : 0, ghist);
         UWIE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_sel_scan, dim3(nbc), dim3(256), 0, st, state, ghist, bitsv[p], 2 * nq, p == 2 ? 1 : 0, os);
+        UWIE_LAUNCH(k_sel_scan, dim3(nbc), dim3(256), 0, st, state, ghist, bitsv[p], 2 * nq, p == 2 ? 1 : 0, os);
         UWIE_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_pct_finish, dim3(cdiv(nbc * nq, 64)), dim3(64), 0, st, os, nbc, fr, d_out);
+    UWIE_LAUNCH(k_pct_finish, dim3(cdiv(nbc * nq, 64)), dim3(64), 0, st, os, nbc, fr, d_out);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_quantise(const float *__restrict__ img,
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                    float *d_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_restore, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
+    UWIE_LAUNCH(k_restore, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
                        d_out);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
@@ -89,7 +89,7 @@ int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A,
 int launch_stretch_apply_f32(const float *d_img, const float *d_pct, int pct_stride, int lo_idx, int hi_idx, float eps,
                              float *d_out, Shape s, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_stretch_apply, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_img, d_pct, pct_stride, lo_idx,
+    UWIE_LAUNCH(k_stretch_apply, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_img, d_pct, pct_stride, lo_idx,
                        hi_idx, eps, (int)s.npx(), d_out);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
@@ -101,14 +101,14 @@ int launch_gamma_f32(const float *d_img, float *d_out, size_t n, double g, int m
     // mode 1: np.power(img, g) with img float32 -> exponent float32(g)      (six_stadigy.py:224)
     // mode 2: np.power(img, 1.0/g): the quotient is a Python float, cast to float32 for a float32 image (ES:284)
     const float e = mode == 1 ? (float)g : (float)(1.0 / g);
-    hipLaunchKernelGGL(k_gamma, dim3(grid_for(n)), dim3(256), 0, st, d_img, d_out, n, e, mode == 2 ? 1 : 0);
+    UWIE_LAUNCH(k_gamma, dim3(grid_for(n)), dim3(256), 0, st, d_img, d_out, n, e, mode == 2 ? 1 : 0);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
 
 int launch_quantise_u8(const float *d_img, uint8_t *d_out, size_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_quantise, dim3(grid_for(n)), dim3(256), 0, st, d_img, d_out, n);
+    UWIE_LAUNCH(k_quantise, dim3(grid_for(n)), dim3(256), 0, st, d_img, d_out, n);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

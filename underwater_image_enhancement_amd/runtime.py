@@ -86,6 +86,22 @@ class Device:
         assert img.dim() == 4 and img.shape[-1] == 3 and img.is_contiguous(), "expected contiguous [B,H,W,3]"
         return int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
 
+    # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
+    def profile(self, on: bool):
+        check(self.lib.uwie_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_rows(self):
+        """Synchronise and return {kernel name: (total ms, launches)} recorded since the last call."""
+        n = self.lib.uwie_profile_collect(self._ctx)
+        if n < 0:
+            check(n)
+        rows = {}
+        name, ms, calls = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int()
+        for i in range(n):
+            check(self.lib.uwie_profile_row(self._ctx, i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(calls)))
+            rows[name.value.decode()] = (ms.value, calls.value)
+        return rows
+
     # ------------------------------------------------------------------ whole pipeline
     def enhance_u8(self, frames, p: UwieParams, want_float: bool = False):
         """frames: uint8 cuda tensor [B,H,W,3] -> (uint8 [B,H,W,3], float32 [B,H,W,3] or None)."""
