@@ -98,7 +98,9 @@ int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipSt
     return launch_stretch_apply_f32(P.F, P.pct, 2, 0, 1, eps, P.F, s, st);
 }
 
-int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, hipStream_t st)
+// Writes the strategy's float image to d_out_f32 and/or its (y*255).astype(u8) image to d_out_u8.
+int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
+            float *d_out_f32, hipStream_t st)
 {
     const size_t n3 = (size_t)s.B * s.npx() * 3;
     const int32_t *kind = nullptr;
@@ -116,15 +118,19 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
         UWIE_TRY(launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
         UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
         UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
-        UWIE_TRY(launch_restore(d_in, kind, P.A, P.t, s, P.F, st));
-        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
+        // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
+        SelectPlan plan;
+        const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
+        UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
+        UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
         if (k == 3) {
-            UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
-        } else {
-            UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
-            if (k == 1) UWIE_TRY(launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st));
+            UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));
+            return launch_tail_plain(P.F, P.pct, 4, eps, 1, s, 0, 1.0, d_out_u8, d_out_f32, st);
         }
-        return UWIE_OK;
+        UWIE_TRY(select_lerp(plan, s, P.pct, st));
+        return launch_tail_clahe(ctx, P.F, P.pct, 2, eps, 0, s, p->clip_limit, p->tiles_x, p->tiles_y, k == 1 ? 1 : 0,
+                                 p->gamma, d_out_u8, d_out_f32, P.scratch, st);
     }
     UWIE_TRY(launch_normalise_correct(d_in, kind, P.F, s, st));
     if (k == 4) {
@@ -139,7 +145,10 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
         UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
         UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
     }
-    return launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st);
+    UWIE_TRY(launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st));
+    if (d_out_u8) UWIE_TRY(launch_quantise_u8(P.F, d_out_u8, n3, st));
+    if (d_out_f32) UWIE_HIP_CHECK(hipMemcpyAsync(d_out_f32, P.F, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return UWIE_OK;
 }
 
 int check_params(const uwie_params *p)
@@ -302,15 +311,10 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
     UWIE_CHECK_WS(c.total());
     hipStream_t st = (hipStream_t)stream;
     if (p->surface == UWIE_SURFACE_SIX) {
-        UWIE_TRY(run_six(ctx, d_in, s, p, P, st));
-    } else {
-        set_error("the enhancement_strategies.py (dict) surface is not wired into uwie_enhance_u8 yet");
-        return UWIE_E_INVALID;
+        return run_six(ctx, d_in, s, p, P, d_out_u8, d_out_f32, st);
     }
-    const size_t n3 = (size_t)batch * s.npx() * 3;
-    if (d_out_u8) UWIE_TRY(launch_quantise_u8(P.F, d_out_u8, n3, st));
-    if (d_out_f32) UWIE_HIP_CHECK(hipMemcpyAsync(d_out_f32, P.F, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return UWIE_OK;
+    set_error("the enhancement_strategies.py (dict) surface is not wired into uwie_enhance_u8 yet");
+    return UWIE_E_INVALID;
 }
 
 /* ---------------------------------------------------------------- stage entry points */

@@ -160,6 +160,32 @@ size_t select_ws_bytes(Shape s);
 int launch_percentiles_f32(const float *d_vals, int planar, Shape s, const double *q_percent, int nq, float *d_out,
                            void *ws, hipStream_t st);
 
+// selection in pieces, for producers that fuse the first histogram sweep (digit = f32_key(v) >> 21, 2048 bins,
+// accumulated into plan.ghist[(b*3 + c) * kSelGroupStride + digit])
+constexpr int kSelGroupStride = 2 * kMaxPct * 2048;
+struct SelectPlan {
+    void *state;
+    uint32_t *ghist;
+    float *os;
+    float t[kMaxPct];
+    int nq;
+};
+int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
+int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
+int select_lerp_chain(const SelectPlan &plan, Shape s, float eps, float *d_pct4, hipStream_t st);   // [B][3][4]
+
+// k_fused.hip: the fused tail of the dehazing strategies
+int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st);
+size_t tail_ws_bytes(Shape s, int tx, int ty);
+// d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
+int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,
+                      Shape s, double clip, int tx, int ty, int gamma_mode, double gamma, uint8_t *d_out_u8,
+                      float *d_out_f32, void *ws, hipStream_t st);
+int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
+                      int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
+
 // k_tail.hip
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                    float *d_out, hipStream_t st);

@@ -28,6 +28,13 @@ __device__ __forceinline__ uint32_t gray_fixed(uint32_t r, uint32_t g, uint32_t 
                        : (r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14;
 }
 
+// order-preserving integer image of a float32 (radix select, k_select.hip): ascending key == ascending value
+__device__ __forceinline__ uint32_t f32_key(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int reflect101(int p, int len)
 {

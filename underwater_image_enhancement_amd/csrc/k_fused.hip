@@ -1,0 +1,341 @@
+// Fused tail of the dehazing strategies (six_stadigy.py:230-259): the stages after the guided filter, arranged
+// so that each global dependency costs exactly one sweep:
+//   k_restore_planar_hist  restore_image (S6:183-188) -> planar float32 + first-digit histogram of the radix select
+//   (k_select.hip)         two more histogram sweeps -> order statistics -> percentiles (S6:196-197, 216-217)
+//   k_stretch_lab_lut      enhance_contrast (S6:198) [+ white_balance (S6:218)] -> (x*255).astype(u8) -> RGB2LAB
+//                          (S6:204) -> LAB bytes + per-tile CLAHE histogram -> clipped, redistributed tile LUT
+//   k_clahe_apply_out      CLAHE interpolation (S6:206) -> LAB2RGB -> /255 (S6:207) [-> x**gamma (S6:224)]
+//                          -> (y*255).astype(u8) (S6:430); everything after LAB2RGB is a 256-entry LUT per launch
+//   k_stretch_out          the CLAHE-free tail (strategy 3): stretch -> white_balance -> output
+// Arithmetic is the same as in the unfused stage kernels (k_tail.hip, k_clahe.hip), operation for operation.
+#include "common.h"
+#include "devutil.h"
+
+namespace uwie {
+
+namespace {
+
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
+#define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+// grid (nblk, B), block 256
+__global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                             const float *__restrict__ A, const double *__restrict__ t,
+                                                             int npx, float *__restrict__ planar,
+                                                             uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t h[3][2048];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < 3 * 2048; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int k = kind ? kind[b] : 0;
+    const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
+    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
+        const uint8_t *q = img + (size_t)p * 3;
+        const double tv = t[(size_t)b * npx + p];
+        const float d0 = px_val(q[0], false) - a0;
+        const float d1 = px_val(q[1], px_atten(k, 1)) - a1;
+        const float d2 = px_val(q[2], px_atten(k, 2)) - a2;
+        const float r0 = clip01((float)((double)d0 / tv + (double)a0));
+        const float r1 = clip01((float)((double)d1 / tv + (double)a1));
+        const float r2 = clip01((float)((double)d2 / tv + (double)a2));
+        o0[p] = r0;
+        o1[p] = r1;
+        o2[p] = r2;
+        atomicAdd(&h[0][f32_key(r0) >> 21], 1u);
+        atomicAdd(&h[1][f32_key(r1) >> 21], 1u);
+        atomicAdd(&h[2][f32_key(r2) >> 21], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * 2048; i += 256) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / 2048) * kSelGroupStride + (i % 2048)], c);
+    }
+}
+
+struct Stretch {  // per image: lo and denominator per channel, for one or two chained stretches
+    float lo1[3], den1[3], lo2[3], den2[3];
+    int two;
+    __device__ __forceinline__ void load(const float *pct, int b, int stride, float eps, int two_)
+    {
+        two = two_;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *p = pct + (size_t)(b * 3 + c) * stride;
+            lo1[c] = p[0];
+            den1[c] = (p[1] - p[0]) + eps;
+            lo2[c] = two ? p[2] : 0.f;
+            den2[c] = two ? (p[3] - p[2]) + eps : 1.f;
+        }
+    }
+    __device__ __forceinline__ float apply(float v, int c) const
+    {
+        v = clip01((v - lo1[c]) / den1[c]);
+        if (two) v = clip01((v - lo2[c]) / den2[c]);
+        return v;
+    }
+};
+
+struct ClaheGeom {
+    int H, W, tx, ty, tw, th, clip;
+    float lutScale;
+};
+
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *wsum)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) incl += wsum[i];
+    return incl;
+}
+
+// grid (tx*ty, B), block 256
+__global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__restrict__ T, const float *__restrict__ planar,
+                                                         const float *__restrict__ pct, int pct_stride, float eps, int two,
+                                                         ClaheGeom g, uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
+{
+    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint16_t s_gamma[256], s_cbrt[3072];
+    __shared__ int s_fwd[9];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+    for (int i = tid; i < 256; i += 256) s_gamma[i] = T->gamma[i];
+    for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
+    if (tid < 9) s_fwd[tid] = T->fwd[tid];
+    Stretch S;
+    S.load(pct, b, pct_stride, eps, two);
+    __syncthreads();
+    const int npx = g.H * g.W;
+    const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
+    uint8_t *labimg = lab + (size_t)b * npx * 3;
+    const int ty = tile / g.tx, txi = tile % g.tx;
+    const int area = g.tw * g.th;
+    constexpr int Lscale = (116 * 255 + 50) / 100;
+    constexpr int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    for (int i = tid; i < area; i += 256) {
+        const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
+        const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
+        const int R = s_gamma[quant_u8(S.apply(r0[p], 0))];
+        const int G = s_gamma[quant_u8(S.apply(r1[p], 1))];
+        const int B = s_gamma[quant_u8(S.apply(r2[p], 2))];
+        const int fX = s_cbrt[UWIE_DESCALE(R * s_fwd[0] + G * s_fwd[1] + B * s_fwd[2], 12)];
+        const int fY = s_cbrt[UWIE_DESCALE(R * s_fwd[3] + G * s_fwd[4] + B * s_fwd[5], 12)];
+        const int fZ = s_cbrt[UWIE_DESCALE(R * s_fwd[6] + G * s_fwd[7] + B * s_fwd[8], 12)];
+        const uint8_t L = sat_u8(UWIE_DESCALE(Lscale * fY + Lshift, 15));
+        atomicAdd(&h[w][L], 1u);
+        if (ey < g.H && ex < g.W) {
+            uint8_t *o = labimg + (size_t)p * 3;
+            o[0] = L;
+            o[1] = sat_u8(UWIE_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
+            o[2] = sat_u8(UWIE_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
+        }
+    }
+    __syncthreads();
+    uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (g.clip > 0) {
+        const uint32_t over = c > (uint32_t)g.clip ? c - g.clip : 0;
+        if (over) c = g.clip;
+        const uint32_t tot = block_incl_scan_256(over, wsum);
+        __syncthreads();
+        if (tid == 255) wsum[0] = tot;
+        __syncthreads();
+        const uint32_t clipped = wsum[0];
+        __syncthreads();
+        const uint32_t batch = clipped / 256, residual = clipped - batch * 256;
+        c += batch;
+        if (residual) {
+            const uint32_t step = max(256u / residual, 1u);
+            if (tid % step == 0 && tid / step < residual) c += 1;
+        }
+    }
+    const uint32_t sum = block_incl_scan_256(c, wsum);
+    lut[((size_t)b * g.tx * g.ty + tile) * 256 + tid] = sat_u8(__float2int_rn((float)sum * g.lutScale));
+}
+
+__device__ __forceinline__ float pow_f32(float x, float e) { return (float)pow((double)x, (double)e); }
+
+// value of the float image for an 8-bit code v after LAB2RGB: v/255 [-> gamma]; and its output quantisation
+__device__ __forceinline__ float final_value(int v, int gamma_mode, float gexp)
+{
+    float y = (float)v / 255.0f;
+    if (gamma_mode == 1) y = pow_f32(y, gexp);
+    else if (gamma_mode == 2) y = clip01(pow_f32(y, gexp));
+    return y;
+}
+
+__device__ __forceinline__ int ab_to_xz(int i)
+{
+    // abToXZ_b of OpenCV's Lab2RGBinteger, evaluated instead of tabulated (C integer division truncates toward 0)
+    return i <= 3390 ? i * 108 / 841 - (1 << 14) * 16 / 116 * 108 / 841 : i * i / (1 << 14) * i / (1 << 14);
+}
+
+// grid-stride over pixels, grid (n, B), block 256
+__global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
+                                                         const uint8_t *__restrict__ lut, ClaheGeom g, int gamma_mode,
+                                                         float gexp, uint8_t *__restrict__ out_u8,
+                                                         float *__restrict__ out_f32)
+{
+    __shared__ int s_ltoyf[512];
+    __shared__ uint8_t s_invgamma[4096];
+    __shared__ int s_inv[9];
+    __shared__ float s_ff[256];
+    __shared__ uint8_t s_fu[256];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int i = tid; i < 512; i += 256) s_ltoyf[i] = T->ltoyf[i];
+    for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
+    if (tid < 9) s_inv[tid] = T->inv[tid];
+    {
+        const float y = final_value(tid, gamma_mode, gexp);
+        s_ff[tid] = y;
+        s_fu[tid] = (uint8_t)quant_u8(y);
+    }
+    __syncthreads();
+    const int npx = g.H * g.W;
+    const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
+    const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
+    constexpr int BASE = 1 << 14;
+    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
+        const int y = p / g.W, x = p % g.W;
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, g.ty - 1);
+        const float txf = (float)x * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf);
+        int tx2 = tx1 + 1;
+        const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+        tx1 = max(tx1, 0);
+        tx2 = min(tx2, g.tx - 1);
+        const uint8_t *q = lab + ((size_t)b * npx + p) * 3;
+        const int v = q[0], aa = q[1], bb = q[2];
+        const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
+        const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
+        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+        const int LL = sat_u8(__float2int_rn(res));
+        // LAB2RGB (Lab2RGBinteger)
+        const int yy = s_ltoyf[LL * 2], ify = s_ltoyf[LL * 2 + 1];
+        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+        const int xx = ab_to_xz(ify + adiv), zz = ab_to_xz(ify - bdiv);
+        const int ro = min(max(UWIE_DESCALE(s_inv[0] * xx + s_inv[1] * yy + s_inv[2] * zz, 14), 0), 4095);
+        const int go = min(max(UWIE_DESCALE(s_inv[3] * xx + s_inv[4] * yy + s_inv[5] * zz, 14), 0), 4095);
+        const int bo = min(max(UWIE_DESCALE(s_inv[6] * xx + s_inv[7] * yy + s_inv[8] * zz, 14), 0), 4095);
+        const int c0 = s_invgamma[ro], c1 = s_invgamma[go], c2 = s_invgamma[bo];
+        const size_t o = ((size_t)b * npx + p) * 3;
+        if (out_u8) {
+            out_u8[o] = s_fu[c0];
+            out_u8[o + 1] = s_fu[c1];
+            out_u8[o + 2] = s_fu[c2];
+        }
+        if (out_f32) {
+            out_f32[o] = s_ff[c0];
+            out_f32[o + 1] = s_ff[c1];
+            out_f32[o + 2] = s_ff[c2];
+        }
+    }
+}
+
+// CLAHE-free tail: planar restored -> stretch [-> stretch] [-> gamma] -> HWC outputs.  grid (n, B)
+__global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ planar, const float *__restrict__ pct,
+                                                     int pct_stride, float eps, int two, int npx, int gamma_mode, float gexp,
+                                                     uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
+{
+    const int b = blockIdx.y;
+    Stretch S;
+    S.load(pct, b, pct_stride, eps, two);
+    const float *r = planar + (size_t)b * 3 * npx;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
+        const size_t o = ((size_t)b * npx + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float y = S.apply(r[(size_t)c * npx + p], c);
+            if (gamma_mode == 1) y = pow_f32(y, gexp);
+            else if (gamma_mode == 2) y = clip01(pow_f32(y, gexp));
+            if (out_u8) out_u8[o + c] = (uint8_t)quant_u8(y);
+            if (out_f32) out_f32[o + c] = y;
+        }
+    }
+}
+
+ClaheGeom make_geom(Shape s, double clip, int tx, int ty)
+{
+    ClaheGeom g;
+    g.H = s.H; g.W = s.W; g.tx = tx; g.ty = ty;
+    int We = s.W, He = s.H;
+    if (s.W % tx != 0 || s.H % ty != 0) {
+        We = s.W + (tx - s.W % tx);
+        He = s.H + (ty - s.H % ty);
+    }
+    g.tw = We / tx;
+    g.th = He / ty;
+    const int area = g.tw * g.th;
+    g.lutScale = (float)(256 - 1) / (float)area;
+    g.clip = 0;
+    if (clip > 0.0) {
+        g.clip = (int)(clip * area / 256);
+        if (g.clip < 1) g.clip = 1;
+    }
+    return g;
+}
+
+float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode == 2 ? (float)(1.0 / g) : 1.0f; }
+
+}  // namespace
+
+int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st)
+{
+    int nblk = 2048 / s.B;
+    nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
+    const int need = cdiv((long long)s.npx(), 256);
+    if (nblk > need) nblk = need;
+    UWIE_LAUNCH(k_restore_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(), d_planar,
+                d_ghist);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+size_t tail_ws_bytes(Shape s, int tx, int ty)
+{
+    Carver c(nullptr);
+    c.take<uint8_t>((size_t)s.B * tx * ty * 256);
+    c.take<uint8_t>((size_t)s.B * s.npx() * 3);
+    return c.total();
+}
+
+int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,
+                      Shape s, double clip, int tx, int ty, int gamma_mode, double gamma, uint8_t *d_out_u8,
+                      float *d_out_f32, void *ws, hipStream_t st)
+{
+    Carver c(ws);
+    uint8_t *lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
+    uint8_t *lab = c.take<uint8_t>((size_t)s.B * s.npx() * 3);
+    const ClaheGeom g = make_geom(s, clip, tx, ty);
+    UWIE_LAUNCH(k_stretch_lab_lut, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, d_pct, pct_stride, eps, two,
+                g, lab, lut);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_clahe_apply_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g,
+                gamma_mode, gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
+                      int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st)
+{
+    UWIE_LAUNCH(k_stretch_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, d_planar, d_pct, pct_stride, eps, two,
+                (int)s.npx(), gamma_mode, gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+}  // namespace uwie

@@ -14,72 +14,105 @@ namespace uwie {
 
 namespace {
 
-// ---- sources for the row pass: fill v[NP] with the plane values at (b, y, x)
+// ---- sources for the row pass.  Raw = what is staged in LDS per pixel; plane(raw, w) = the value of plane w.
 struct SrcPlanes1 {
     const double *p;
     int H, W;
     static constexpr int NP = 1;
-    __device__ __forceinline__ void load(const double *, int b, int y, int x, double *v) const
-    {
-        v[0] = p[((size_t)b * H + y) * W + x];
-    }
+    struct Raw {
+        double v;
+    };
+    __device__ __forceinline__ Raw load(int b, int y, int x) const { return Raw{p[((size_t)b * H + y) * W + x]}; }
+    __device__ static __forceinline__ double plane(const Raw &r, int, const double *) { return r.v; }
 };
 struct SrcPlanes2 {
     const double *p0, *p1;
     int H, W;
     static constexpr int NP = 2;
-    __device__ __forceinline__ void load(const double *, int b, int y, int x, double *v) const
+    struct Raw {
+        double a, b;
+    };
+    __device__ __forceinline__ Raw load(int b, int y, int x) const
     {
         const size_t i = ((size_t)b * H + y) * W + x;
-        v[0] = p0[i];
-        v[1] = p1[i];
+        return Raw{p0[i], p1[i]};
     }
+    __device__ static __forceinline__ double plane(const Raw &r, int w, const double *) { return w == 0 ? r.a : r.b; }
 };
 struct SrcGuide {  // I = gray/255 (float64), p = t0 (float32 -> float64); planes I, p, I*p, I*I (six_stadigy.py:28-36)
     const uint8_t *gray;
     const float *t0;
     int H, W;
     static constexpr int NP = 4;
-    __device__ __forceinline__ void load(const double *ilut, int b, int y, int x, double *v) const
+    struct Raw {
+        float t0;
+        uint32_t g;
+    };
+    __device__ __forceinline__ Raw load(int b, int y, int x) const
     {
         const size_t i = ((size_t)b * H + y) * W + x;
-        const double I = ilut[gray[i]], p = (double)t0[i];
-        v[0] = I;
-        v[1] = p;
-        v[2] = I * p;
-        v[3] = I * I;
+        return Raw{t0[i], gray[i]};
+    }
+    __device__ static __forceinline__ double plane(const Raw &r, int w, const double *ilut)
+    {
+        const double I = ilut[r.g], p = (double)r.t0;
+        return w == 0 ? I : w == 1 ? p : w == 2 ? I * p : I * I;
     }
 };
 
+// Row pass: RowSum<double,double> of cv2.boxFilter.  One workgroup owns 64 rows of one image; wave w owns plane w
+// and lane r owns row r, so every row's running sum is the literal left-to-right chain
+//     s = E[0] + ... + E[k-1];   out[0] = s;   s += E[x+k] - E[x];   out[x+1] = s
+// while all HBM traffic is coalesced: 64x16 tiles of the source are staged through LDS (a "lead" tile at x+k and a
+// "trail" tile at x, both read row-contiguously), and each wave's 64x16 result tile goes back out row-contiguously.
+constexpr int kTR = 64, kTC = 16, kTS = kTC + 1;  // tile rows, tile columns, padded LDS row stride
+
 template <class Src>
-__global__ void __launch_bounds__(64) k_box_rows(Src src, double *__restrict__ out, size_t plane_stride, int B, int k)
+__global__ void __launch_bounds__(64 * Src::NP) k_box_rows(Src src, double *__restrict__ out, size_t plane_stride, int k)
 {
-    constexpr int NP = Src::NP;
+    constexpr int NP = Src::NP, NT = 64 * NP;
+    using Raw = typename Src::Raw;
     __shared__ double ilut[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
-    __syncthreads();
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    const int H = src.H, W = src.W;
-    if (row >= B * H) return;
-    const int b = row / H, y = row % H, a = k / 2;
-    double s[NP], lead[NP], trail[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) s[p] = 0.0;
-    for (int j = 0; j < k; ++j) {
-        src.load(ilut, b, y, reflect101(j - a, W), lead);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) s[p] += lead[p];
+    __shared__ Raw lead[kTR * kTS], trail[kTR * kTS];
+    __shared__ double otile[NP][kTR * kTS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 256; i += NT) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
+    const int b = blockIdx.y, y0 = blockIdx.x * kTR, H = src.H, W = src.W, a = k / 2;
+    const int nrows = min(kTR, H - y0);
+    // dst[r][c] = E[j0 + c]: the border-extended row (BORDER_REFLECT_101, anchor a), j in [0, W + k - 1)
+    auto stage = [&](Raw *dst, int j0) {
+        for (int e = tid; e < kTR * kTC; e += NT) {
+            const int r = e / kTC, c = e % kTC, j = j0 + c;
+            if (r < nrows && j >= 0 && j < W + k - 1) dst[r * kTS + c] = src.load(b, y0 + r, reflect101(j - a, W));
+        }
+    };
+    double s = 0.0;
+    for (int j0 = 0; j0 < k; j0 += kTC) {
+        __syncthreads();
+        stage(lead, j0);
+        __syncthreads();
+        if (lane < nrows)
+            for (int c = 0; c < kTC && j0 + c < k; ++c) s += Src::plane(lead[lane * kTS + c], w, ilut);
     }
-    double *o = out + (size_t)row * W;
+    double *obase = out + (size_t)w * plane_stride + ((size_t)b * H + y0) * W;
+    for (int col0 = 0; col0 < W; col0 += kTC) {
+        __syncthreads();
+        stage(lead, col0 - 1 + k);
+        stage(trail, col0 - 1);
+        __syncthreads();
+        if (lane < nrows) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) o[p * plane_stride] = s[p];
-    for (int x = 0; x < W - 1; ++x) {
-        src.load(ilut, b, y, reflect101(x + k - a, W), lead);
-        src.load(ilut, b, y, reflect101(x - a, W), trail);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            s[p] += lead[p] - trail[p];
-            o[p * plane_stride + x + 1] = s[p];
+            for (int c = 0; c < kTC; ++c) {
+                const int col = col0 + c;
+                if (col > 0 && col < W)
+                    s += Src::plane(lead[lane * kTS + c], w, ilut) - Src::plane(trail[lane * kTS + c], w, ilut);
+                otile[w][lane * kTS + c] = s;
+            }
+        }
+        __syncthreads();
+        for (int e = lane; e < kTR * kTC; e += 64) {
+            const int r = e / kTC, c = e % kTC;
+            if (r < nrows && col0 + c < W) obase[(size_t)r * W + col0 + c] = otile[w][r * kTS + c];
         }
     }
 }
@@ -192,8 +225,7 @@ int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, vo
     Carver c(ws);
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n);
-    UWIE_LAUNCH(k_box_rows<SrcPlanes1>, dim3(cdiv((long long)s.B * s.H, 64)), dim3(64), 0, st,
-                       SrcPlanes1{d_src, s.H, s.W}, rs, n, s.B, k);
+    UWIE_LAUNCH(k_box_rows<SrcPlanes1>, dim3(cdiv(s.H, kTR), s.B), dim3(64), 0, st, SrcPlanes1{d_src, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiStore1>, dim3(cdiv((long long)s.B * s.W, 64)), dim3(64), 0, st, rs, n,
                        EpiStore1{d_dst}, s.B, s.H, s.W, k);
@@ -215,12 +247,12 @@ int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, doub
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
-    const dim3 grows(cdiv((long long)s.B * s.H, 64)), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
-    UWIE_LAUNCH(k_box_rows<SrcGuide>, grows, blk, 0, st, SrcGuide{d_gray, d_t0, s.H, s.W}, rs, n, s.B, k);
+    const dim3 grows(cdiv(s.H, kTR), s.B), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
+    UWIE_LAUNCH(k_box_rows<SrcGuide>, grows, dim3(256), 0, st, SrcGuide{d_gray, d_t0, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_rows<SrcPlanes2>, grows, blk, 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, s.B, k);
+    UWIE_LAUNCH(k_box_rows<SrcPlanes2>, grows, dim3(128), 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
