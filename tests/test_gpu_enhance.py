@@ -91,3 +91,46 @@ def test_float_surface_mirrors_reference_api(uw, orc):
         uw.SixStrategies.strategy2_medium_dehazing(rng.random((8, 8, 3)).astype(np.float32))
     with pytest.raises(ValueError):
         uw.EnhancementStrategies.apply_strategy(x, "no_such_strategy", {})
+
+
+# ------------------------------------------------------------------ enhancement_strategies.py (dict) surface
+@pytest.mark.parametrize("name", ["strong_dehazing", "medium_dehazing", "light_enhancement", "clahe_enhancement",
+                                  "histogram_equalization"])
+def test_dict_surface_matches_oracle(uw, orc, name):
+    """apply_strategy(img, name, Config.STRATEGIES[name]) (ES:477-508, config.py:28-75) and the in-code defaults."""
+    frames = frames_for_tests(np.random.default_rng(4242))
+    frames.pop("tiny_5x7")
+    ES = orc.DictStrategyOracle
+    for params in (orc.CONFIG_STRATEGIES[name], {}):
+        for tag, u8 in frames.items():
+            x = orc.normalise_u8(u8)
+            want = ES.run(x, name, params)  # float64 image of the reference
+            got = uw.EnhancementStrategies.apply_strategy(x, name, params)
+            assert got.dtype == np.float32 and got.shape == want.shape
+            # u8 image as main.py:155 makes it; the device also quantises in float64
+            dev = uw.get_device(0)
+            over = {}
+            for key, field in (("omega", "omega"), ("guided_radius", "gf_ksize"), ("L_low", "L_low"), ("L_high", "L_high"),
+                               ("clip_limit", "clip_limit"), ("gamma", "gamma")):
+                if key in params:
+                    over[field] = params[key]
+            over["apply_gamma"] = int(bool(params.get("apply_gamma", False)))
+            p = dev.params(1, {"strong_dehazing": 0, "medium_dehazing": 1, "light_enhancement": 2, "clahe_enhancement": 3,
+                               "histogram_equalization": 4}[name], **over)
+            out_u8, out_f = dev.enhance_u8(dev.tensor(u8[None]), p, want_float=True)
+            d = np.abs(out_u8[0].cpu().numpy().astype(int) - (want * 255).astype(np.uint8).astype(int))
+            assert d.max() <= 1, f"{name} on {tag}: {d.max()} LSB"
+            if not params.get("apply_gamma", False):  # without pow everything is reproduced bit for bit
+                assert d.max() == 0, f"{name} on {tag}: {np.count_nonzero(d)} bytes differ"
+                assert np.array_equal(got, want.astype(np.float32))
+            else:
+                assert np.abs(got.astype(np.float64) - want).max() < 1e-6
+
+
+def test_dict_surface_error_behaviour(uw, orc):
+    rng = np.random.default_rng(5)
+    x = orc.normalise_u8(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        uw.EnhancementStrategies.apply_strategy(x, "weak_dehazing", {})  # commented out in the reference (ES:494-496)
+    bad = rng.random((16, 16, 3)).astype(np.float32)  # not u8-derived: swallowed, input returned (ES:503-508)
+    assert uw.EnhancementStrategies.apply_strategy(bad, "strong_dehazing", {}) is bad

@@ -46,7 +46,9 @@ struct Pipe {
     int32_t *kind;
     float *A;
     float *pct;
-    float *F;       // float32 HWC working image
+    float *F;       // float32 working image (planar on the dehazing paths)
+    double *F64;    // float64 planar image (dict-surface dehazing only)
+    double *pct64;
     uint8_t *gray;
     float *t0;
     double *t;
@@ -77,8 +79,14 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     P.kind = c.take<int32_t>(s.B);
     P.A = c.take<float>((size_t)s.B * 3);
     P.pct = c.take<float>((size_t)s.B * 3 * kMaxPct);
-    P.F = c.take<float>(n * 3);
     const bool dz = !p || dehazes(p);
+    const bool dict_dz = p && p->surface == UWIE_SURFACE_DICT && dz;
+    if (dict_dz) {
+        P.F64 = c.take<double>(n * 3);
+        P.pct64 = c.take<double>((size_t)s.B * 3 * kMaxPct);
+    } else {
+        P.F = c.take<float>(n * 3);
+    }
     if (dz) {
         P.gray = c.take<uint8_t>(n);
         P.t0 = c.take<float>(n);
@@ -87,6 +95,8 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     const int tx = p ? p->tiles_x : 8, ty = p ? p->tiles_y : 8;
     P.scratch_bytes = max5(cast_ws_bytes(s), dz ? airlight_ws_bytes(s) : 0, dz ? guided_ws_bytes(s) : 0,
                            select_ws_bytes(s), clahe_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8));
+    const size_t cw = codes_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8);
+    if (cw > P.scratch_bytes) P.scratch_bytes = cw;
     P.scratch = c.take<char>(P.scratch_bytes);
     return P;
 }
@@ -102,7 +112,6 @@ int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipSt
 int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
             float *d_out_f32, hipStream_t st)
 {
-    const size_t n3 = (size_t)s.B * s.npx() * 3;
     const int32_t *kind = nullptr;
     if (p->forced_cast >= 0) {
         UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
@@ -132,23 +141,25 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
         return launch_tail_clahe(ctx, P.F, P.pct, 2, eps, 0, s, p->clip_limit, p->tiles_x, p->tiles_y, k == 1 ? 1 : 0,
                                  p->gamma, d_out_u8, d_out_f32, P.scratch, st);
     }
-    UWIE_TRY(launch_normalise_correct(d_in, kind, P.F, s, st));
-    if (k == 4) {
-        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
-        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
-        UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
-    } else if (k == 5) {
-        UWIE_TRY(stage_stretch(P, s, p->wb_percentile, 100 - p->wb_percentile, eps, st));
-        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
-        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
-    } else {
-        UWIE_TRY(stage_stretch(P, s, p->L_low, p->L_high, eps, st));
-        UWIE_TRY(launch_clahe_f32(ctx, P.F, P.F, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
-    }
-    UWIE_TRY(launch_gamma_f32(P.F, P.F, n3, p->gamma, 1, st));
-    if (d_out_u8) UWIE_TRY(launch_quantise_u8(P.F, d_out_u8, n3, st));
-    if (d_out_f32) UWIE_HIP_CHECK(hipMemcpyAsync(d_out_f32, P.F, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return UWIE_OK;
+    // strategies 4-6 never leave 8-bit data for long: evaluated as per-image LUT chains (k_codes.hip)
+    return launch_code_strategy(ctx, d_in, kind, s, p, d_out_u8, d_out_f32, P.scratch, st);
+}
+
+// enhancement_strategies.py apply_strong/medium/light (ES:350-444) on the uncorrected frame
+int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
+                    float *d_out_f32, hipStream_t st)
+{
+    UWIE_TRY(launch_quant_gray(d_in, nullptr, P.gray, s, p->gray_shift, st));
+    UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
+    UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
+    UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+    SelectPlan plan;
+    const double q[2] = {p->L_low, p->L_high};
+    UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
+    UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st));
+    UWIE_TRY(select_run64(plan, P.F64, 1, s, true, st));
+    UWIE_TRY(select_lerp64(plan, s, P.pct64, st));
+    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st);
 }
 
 int check_params(const uwie_params *p)
@@ -313,8 +324,8 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
     if (p->surface == UWIE_SURFACE_SIX) {
         return run_six(ctx, d_in, s, p, P, d_out_u8, d_out_f32, st);
     }
-    set_error("the enhancement_strategies.py (dict) surface is not wired into uwie_enhance_u8 yet");
-    return UWIE_E_INVALID;
+    if (!dehazes(p)) return launch_code_strategy(ctx, d_in, nullptr, s, p, d_out_u8, d_out_f32, P.scratch, st);
+    return run_dict_dehaze(ctx, d_in, s, p, P, d_out_u8, d_out_f32, st);
 }
 
 /* ---------------------------------------------------------------- stage entry points */

@@ -166,14 +166,19 @@ constexpr int kSelGroupStride = 2 * kMaxPct * 2048;
 struct SelectPlan {
     void *state;
     uint32_t *ghist;
-    float *os;
-    float t[kMaxPct];
+    void *os;              // order statistics, float or double [B*3][8]
+    double t[kMaxPct];     // lerp weights (exactly representable values of the data's dtype)
     int nq;
+    bool is64;
 };
 int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
 int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
 int select_lerp_chain(const SelectPlan &plan, Shape s, float eps, float *d_pct4, hipStream_t st);   // [B][3][4]
+// float64 data (ES surface): first digit = f64_key(v) >> 53
+int select_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+int select_run64(const SelectPlan &plan, const double *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
+int select_lerp64(const SelectPlan &plan, Shape s, double *d_out, hipStream_t st);
 
 // k_fused.hip: the fused tail of the dehazing strategies
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
@@ -185,6 +190,18 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
                       float *d_out_f32, void *ws, hipStream_t st);
 int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
                       int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
+// ES surface (float64): recover_image (ES:237-249) -> planar float64 + first select digit; color_enhancement
+// (ES:269-270, eps 1e-10) [-> gamma_correction (ES:284-285)] -> (y*255).astype(u8) (main.py:155) / float32 copy
+int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
+                                 uint32_t *d_ghist, hipStream_t st);
+int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
+                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
+
+// k_codes.hip: strategies 4-6 of six_stadigy.py and the clahe / histogram-equalisation strategies of
+// enhancement_strategies.py, evaluated on 8-bit codes (per image and channel LUT chains + histograms)
+size_t codes_ws_bytes(Shape s, int tx, int ty);
+int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st);
 
 // k_tail.hip
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,

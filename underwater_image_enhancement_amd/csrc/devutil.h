@@ -35,6 +35,12 @@ __device__ __forceinline__ uint32_t f32_key(float v)
     return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
 }
 
+__device__ __forceinline__ uint64_t f64_key(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return b ^ ((b >> 63) ? 0xffffffffffffffffull : 0x8000000000000000ull);
+}
+
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __device__ __forceinline__ int reflect101(int p, int len)
 {

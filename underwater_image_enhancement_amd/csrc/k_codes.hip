@@ -1,0 +1,543 @@
+// "Code-domain" evaluation of the strategies that never leave 8-bit data for long:
+//   six_stadigy.py strategies 4, 5, 6 (S6:262-285) and enhancement_strategies.py's clahe_enhancement /
+//   histogram_equalization strategies (ES:400-420, 461-474).
+// Between the u8 input frame and CLAHE, and between LAB2RGB's u8 output and the final quantisation, every stage
+// (u8/255, colour correction, percentile stretch, white balance, equalizeHist, gamma, quantisation) is a monotone
+// per-channel map of an 8-bit code.  So the float image never has to exist: k_code_chain evaluates the chain on the
+// 256 possible codes of one (image, channel) -- in float32 for the S6 surface, float64 for the ES surface, in the
+// reference's operation order -- and np.percentile's order statistics come from the 256-bin histogram (a monotone map
+// keeps the order, so the k-th smallest value is the map of the k-th smallest code).  The frame is then touched once
+// per stage that mixes channels or neighbours (CLAHE) plus one LUT application.
+#include <cmath>
+
+#include "common.h"
+#include "devutil.h"
+
+namespace uwie {
+
+namespace {
+
+__device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
+#define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+// ------------------------------------------------------------------ histograms of u8 HWC frames
+// grid (nblk, B): hist[b][c][256] += counts
+__global__ void __launch_bounds__(256) k_frame_hist(const uint8_t *__restrict__ in, int npx, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[4][768];
+    const int b = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < 4 * 768; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
+        const uint8_t *q = img + (size_t)p * 3;
+        atomicAdd(&h[w][q[0]], 1u);
+        atomicAdd(&h[w][256 + q[1]], 1u);
+        atomicAdd(&h[w][512 + q[2]], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 768; i += 256) {
+        const uint32_t c = h[0][i] + h[1][i] + h[2][i] + h[3][i];
+        if (c) atomicAdd(&hist[(size_t)b * 768 + i], c);
+    }
+}
+
+// ------------------------------------------------------------------ the chain
+enum { OP_INIT = 1, OP_INITQUANT, OP_FROMCODE, OP_QUANT, OP_EQUALIZE, OP_STRETCH, OP_GAMMA };
+struct ChainOp {
+    int op, mode;
+    uint32_t rank[4];  // STRETCH: prev/next of the low percentile, prev/next of the high percentile
+    double t[2];       // STRETCH: lerp weights; GAMMA: t[0] = exponent
+};
+struct ChainProg {
+    int nops;
+    ChainOp ops[6];
+    double eps;
+};
+
+template <typename T>
+__device__ __forceinline__ T np_lerp_t(T a, T b, T t)
+{
+    const T diff = b - a;
+    T r = a + diff * t;
+    if (t >= (T)0.5) r = b - diff * ((T)1 - t);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *wsum)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    for (int i = 0; i < w; ++i) incl += wsum[i];
+    return incl;
+}
+
+// grid (3, B), block 256: thread u evaluates the chain for input code u of channel blockIdx.x
+template <typename T>
+__global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__ hist, const int32_t *__restrict__ kind,
+                                                    ChainProg prog, uint8_t *__restrict__ lut_code,
+                                                    float *__restrict__ lut_val)
+{
+    __shared__ uint32_t wsum[4], eqh[256], total_px;
+    __shared__ T os[4];
+    __shared__ int first;
+    const int c = blockIdx.x, b = blockIdx.y, u = threadIdx.x;
+    const bool atten = px_atten(kind ? kind[b] : 0, c);
+    const uint32_t h = hist[(size_t)(b * 3 + c) * 256 + u];
+    const uint32_t incl = block_incl_scan_256(h, wsum);
+    const uint32_t excl = incl - h;
+    if (u == 255) total_px = incl;
+    __syncthreads();
+    T val = 0;
+    int code = u;
+    for (int k = 0; k < prog.nops; ++k) {
+        const ChainOp &op = prog.ops[k];
+        switch (op.op) {
+        case OP_INIT:  // x = u8/255 [* 0.85]: float32 like the reference frame
+            val = (T)px_val(u, atten);
+            break;
+        case OP_INITQUANT:  // (x * 255).astype(u8) of the float32 frame
+            code = quant_u8(px_val(u, atten));
+            break;
+        case OP_FROMCODE:  // .astype(T) / 255.0
+            val = (T)code / (T)255;
+            break;
+        case OP_QUANT:  // (val * 255).astype(u8), in val's precision
+            code = (int)(val * (T)255) & 0xff;
+            break;
+        case OP_EQUALIZE: {  // cv2.equalizeHist on the current codes (ES:343)
+            __syncthreads();
+            eqh[u] = 0;
+            if (u == 0) first = 256;
+            __syncthreads();
+            if (h) atomicAdd(&eqh[code], h);
+            __syncthreads();
+            const uint32_t cnt = eqh[u];
+            if (cnt) atomicMin(&first, u);
+            __syncthreads();
+            const int i0 = first;
+            const uint32_t c0 = eqh[i0];
+            const uint32_t cum = block_incl_scan_256(u > i0 ? cnt : 0, wsum);
+            int mapped;
+            if (c0 == total_px) {
+                mapped = i0;  // constant plane: dst.setTo(i0)
+            } else {
+                const float scale = (256 - 1.f) / (float)(int)(total_px - c0);
+                mapped = u <= i0 ? 0 : sat_u8(__float2int_rn((float)cum * scale));
+            }
+            __syncthreads();
+            eqh[u] = (uint32_t)mapped;  // reuse as the equalisation LUT
+            __syncthreads();
+            code = (int)eqh[code];
+            __syncthreads();
+            break;
+        }
+        case OP_STRETCH: {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (h && excl <= op.rank[j] && op.rank[j] < incl) os[j] = val;
+            __syncthreads();
+            const T lo = np_lerp_t<T>(os[0], os[1], (T)op.t[0]), hi = np_lerp_t<T>(os[2], os[3], (T)op.t[1]);
+            const T v = (val - lo) / ((hi - lo) + (T)prog.eps);
+            val = v < (T)0 ? (T)0 : v > (T)1 ? (T)1 : v;
+            break;
+        }
+        case OP_GAMMA: {
+            T v;
+            if (sizeof(T) == 4) v = (T)(float)pow((double)val, (double)(float)op.t[0]);  // float32 power, rounded once
+            else v = (T)pow((double)val, op.t[0]);
+            if (op.mode == 2) v = v < (T)0 ? (T)0 : v > (T)1 ? (T)1 : v;
+            val = v;
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    if (lut_code) lut_code[(size_t)(b * 3 + c) * 256 + u] = (uint8_t)code;
+    if (lut_val) lut_val[(size_t)(b * 3 + c) * 256 + u] = (float)val;
+}
+
+// ------------------------------------------------------------------ frame kernels
+struct ClaheGeom {
+    int H, W, tx, ty, tw, th, clip;
+    float lutScale;
+};
+
+// u8 frame --(per image/channel code LUT)--> RGB2LAB -> LAB bytes + tile histogram -> tile LUT.  grid (tiles, B)
+__global__ void __launch_bounds__(256) k_codes_lab_lut(const LabTables *__restrict__ T, const uint8_t *__restrict__ in,
+                                                       const uint8_t *__restrict__ code_lut, ClaheGeom g,
+                                                       uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
+{
+    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint16_t s_gamma[256], s_cbrt[3072];
+    __shared__ int s_fwd[9];
+    __shared__ uint8_t s_code[768];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
+    s_gamma[tid] = T->gamma[tid];
+    for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
+    for (int i = tid; i < 768; i += 256) s_code[i] = code_lut[(size_t)b * 768 + i];
+    if (tid < 9) s_fwd[tid] = T->fwd[tid];
+    __syncthreads();
+    const int npx = g.H * g.W;
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    uint8_t *labimg = lab + (size_t)b * npx * 3;
+    const int ty = tile / g.tx, txi = tile % g.tx;
+    const int area = g.tw * g.th;
+    constexpr int Lscale = (116 * 255 + 50) / 100;
+    constexpr int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    for (int i = tid; i < area; i += 256) {
+        const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
+        const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
+        const uint8_t *q = img + (size_t)p * 3;
+        const int R = s_gamma[s_code[q[0]]], G = s_gamma[s_code[256 + q[1]]], B = s_gamma[s_code[512 + q[2]]];
+        const int fX = s_cbrt[UWIE_DESCALE(R * s_fwd[0] + G * s_fwd[1] + B * s_fwd[2], 12)];
+        const int fY = s_cbrt[UWIE_DESCALE(R * s_fwd[3] + G * s_fwd[4] + B * s_fwd[5], 12)];
+        const int fZ = s_cbrt[UWIE_DESCALE(R * s_fwd[6] + G * s_fwd[7] + B * s_fwd[8], 12)];
+        const uint8_t L = sat_u8(UWIE_DESCALE(Lscale * fY + Lshift, 15));
+        atomicAdd(&h[w][L], 1u);
+        if (ey < g.H && ex < g.W) {
+            uint8_t *o = labimg + (size_t)p * 3;
+            o[0] = L;
+            o[1] = sat_u8(UWIE_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
+            o[2] = sat_u8(UWIE_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
+        }
+    }
+    __syncthreads();
+    uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (g.clip > 0) {
+        const uint32_t over = c > (uint32_t)g.clip ? c - g.clip : 0;
+        if (over) c = g.clip;
+        const uint32_t tot = block_incl_scan_256(over, wsum);
+        __syncthreads();
+        if (tid == 255) wsum[0] = tot;
+        __syncthreads();
+        const uint32_t clipped = wsum[0];
+        __syncthreads();
+        const uint32_t batch = clipped / 256, residual = clipped - batch * 256;
+        c += batch;
+        if (residual) {
+            const uint32_t step = max(256u / residual, 1u);
+            if (tid % step == 0 && tid / step < residual) c += 1;
+        }
+    }
+    const uint32_t sum = block_incl_scan_256(c, wsum);
+    lut[((size_t)b * g.tx * g.ty + tile) * 256 + tid] = sat_u8(__float2int_rn((float)sum * g.lutScale));
+}
+
+__device__ __forceinline__ int ab_to_xz(int i)
+{
+    return i <= 3390 ? i * 108 / 841 - (1 << 14) * 16 / 116 * 108 / 841 : i * i / (1 << 14) * i / (1 << 14);
+}
+
+// CLAHE blend -> LAB2RGB -> RGB codes.  Either the codes go out through the final per-(image, channel) LUTs
+// (fin_code / fin_val given), or they are stored raw together with their per-channel histogram (codes_out / hist)
+// because the rest of the chain needs percentiles of them.  grid (n, B)
+__global__ void __launch_bounds__(256) k_clahe_apply_codes(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
+                                                           const uint8_t *__restrict__ lut, ClaheGeom g,
+                                                           const uint8_t *__restrict__ fin_code,
+                                                           const float *__restrict__ fin_val, uint8_t *__restrict__ out_u8,
+                                                           float *__restrict__ out_f32, uint8_t *__restrict__ codes_out,
+                                                           uint32_t *__restrict__ hist)
+{
+    __shared__ int s_ltoyf[512];
+    __shared__ uint8_t s_invgamma[4096];
+    __shared__ int s_inv[9];
+    __shared__ float s_ff[768];
+    __shared__ uint8_t s_fu[768];
+    __shared__ uint32_t h[4][768];
+    const int tid = threadIdx.x, b = blockIdx.y, w = tid >> 6;
+    for (int i = tid; i < 512; i += 256) s_ltoyf[i] = T->ltoyf[i];
+    for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
+    if (tid < 9) s_inv[tid] = T->inv[tid];
+    for (int i = tid; i < 768; i += 256) {
+        s_fu[i] = fin_code ? fin_code[(size_t)b * 768 + i] : (uint8_t)0;
+        s_ff[i] = fin_val ? fin_val[(size_t)b * 768 + i] : 0.f;
+    }
+    if (hist)
+        for (int i = tid; i < 4 * 768; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int npx = g.H * g.W;
+    const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
+    const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
+    constexpr int BASE = 1 << 14;
+    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
+        const int y = p / g.W, x = p % g.W;
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, g.ty - 1);
+        const float txf = (float)x * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf);
+        int tx2 = tx1 + 1;
+        const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+        tx1 = max(tx1, 0);
+        tx2 = min(tx2, g.tx - 1);
+        const uint8_t *q = lab + ((size_t)b * npx + p) * 3;
+        const int v = q[0], aa = q[1], bb = q[2];
+        const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
+        const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
+        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+        const int LL = sat_u8(__float2int_rn(res));
+        const int yy = s_ltoyf[LL * 2], ify = s_ltoyf[LL * 2 + 1];
+        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+        const int xx = ab_to_xz(ify + adiv), zz = ab_to_xz(ify - bdiv);
+        const int ro = min(max(UWIE_DESCALE(s_inv[0] * xx + s_inv[1] * yy + s_inv[2] * zz, 14), 0), 4095);
+        const int go = min(max(UWIE_DESCALE(s_inv[3] * xx + s_inv[4] * yy + s_inv[5] * zz, 14), 0), 4095);
+        const int bo = min(max(UWIE_DESCALE(s_inv[6] * xx + s_inv[7] * yy + s_inv[8] * zz, 14), 0), 4095);
+        const int c0 = s_invgamma[ro], c1 = 256 + s_invgamma[go], c2 = 512 + s_invgamma[bo];
+        const size_t o = ((size_t)b * npx + p) * 3;
+        if (codes_out) {
+            codes_out[o] = (uint8_t)c0;
+            codes_out[o + 1] = (uint8_t)c1;
+            codes_out[o + 2] = (uint8_t)c2;
+        }
+        if (hist) {
+            atomicAdd(&h[w][c0], 1u);
+            atomicAdd(&h[w][c1], 1u);
+            atomicAdd(&h[w][c2], 1u);
+        }
+        if (out_u8) {
+            out_u8[o] = s_fu[c0];
+            out_u8[o + 1] = s_fu[c1];
+            out_u8[o + 2] = s_fu[c2];
+        }
+        if (out_f32) {
+            out_f32[o] = s_ff[c0];
+            out_f32[o + 1] = s_ff[c1];
+            out_f32[o + 2] = s_ff[c2];
+        }
+    }
+    if (hist) {
+        __syncthreads();
+        for (int i = tid; i < 768; i += 256) {
+            const uint32_t c = h[0][i] + h[1][i] + h[2][i] + h[3][i];
+            if (c) atomicAdd(&hist[(size_t)b * 768 + i], c);
+        }
+    }
+}
+
+// u8 HWC codes -> outputs through per-(image, channel) LUTs.  grid (n, B)
+__global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ codes, const uint8_t *__restrict__ fin_code,
+                                                    const float *__restrict__ fin_val, int npx,
+                                                    uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
+{
+    __shared__ float s_ff[768];
+    __shared__ uint8_t s_fu[768];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int i = tid; i < 768; i += 256) {
+        s_fu[i] = fin_code[(size_t)b * 768 + i];
+        s_ff[i] = fin_val[(size_t)b * 768 + i];
+    }
+    __syncthreads();
+    const size_t base = (size_t)b * npx * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < (size_t)npx * 3; i += (size_t)gridDim.x * 256) {
+        const int idx = (int)(i % 3) * 256 + codes[base + i];
+        if (out_u8) out_u8[base + i] = s_fu[idx];
+        if (out_f32) out_f32[base + i] = s_ff[idx];
+    }
+}
+
+ClaheGeom make_geom(Shape s, double clip, int tx, int ty)
+{
+    ClaheGeom g;
+    g.H = s.H; g.W = s.W; g.tx = tx; g.ty = ty;
+    int We = s.W, He = s.H;
+    if (s.W % tx != 0 || s.H % ty != 0) {
+        We = s.W + (tx - s.W % tx);
+        He = s.H + (ty - s.H % ty);
+    }
+    g.tw = We / tx;
+    g.th = He / ty;
+    const int area = g.tw * g.th;
+    g.lutScale = (float)(256 - 1) / (float)area;
+    g.clip = 0;
+    if (clip > 0.0) {
+        g.clip = (int)(clip * area / 256);
+        if (g.clip < 1) g.clip = 1;
+    }
+    return g;
+}
+
+// np.percentile's index arithmetic: float32 for float32 data (S6 surface), float64 for float64 data (ES surface)
+void stretch_op(ChainOp *op, long long n, double lo_pct, double hi_pct, bool f64)
+{
+    op->op = OP_STRETCH;
+    op->mode = 0;
+    const double q[2] = {lo_pct, hi_pct};
+    for (int j = 0; j < 2; ++j) {
+        if (f64) {
+            const double qq = q[j] / 100.0, nm1 = (double)(n - 1), vi = nm1 * qq, p = std::floor(vi);
+            if (vi >= nm1) {
+                op->rank[2 * j] = op->rank[2 * j + 1] = (uint32_t)(n - 1);
+                op->t[j] = 0.0;
+            } else {
+                op->rank[2 * j] = (uint32_t)p;
+                op->rank[2 * j + 1] = (uint32_t)p + 1;
+                op->t[j] = vi - p;
+            }
+        } else {
+            const float qq = (float)q[j] / 100.0f, nm1 = (float)(n - 1), vi = nm1 * qq, p = std::floor(vi);
+            if (vi >= nm1) {
+                op->rank[2 * j] = op->rank[2 * j + 1] = (uint32_t)(n - 1);
+                op->t[j] = 0.0;
+            } else {
+                op->rank[2 * j] = (uint32_t)p;
+                op->rank[2 * j + 1] = (uint32_t)p + 1;
+                op->t[j] = (double)(vi - p);
+            }
+        }
+    }
+}
+
+ChainOp simple_op(int op, int mode = 0, double v = 0.0)
+{
+    ChainOp o{};
+    o.op = op;
+    o.mode = mode;
+    o.t[0] = v;
+    return o;
+}
+
+struct CodeBufs {
+    uint32_t *hist_in, *hist_mid;  // [B][3][256]
+    uint8_t *lut_a_code;           // code LUT feeding CLAHE
+    uint8_t *fin_code;
+    float *fin_val;
+    uint8_t *tile_lut, *lab, *codes;
+};
+
+CodeBufs carve_codes(Carver &c, Shape s, int tx, int ty)
+{
+    CodeBufs b;
+    const size_t n3 = (size_t)s.B * s.npx() * 3;
+    b.hist_in = c.take<uint32_t>((size_t)s.B * 768);
+    b.hist_mid = c.take<uint32_t>((size_t)s.B * 768);
+    b.lut_a_code = c.take<uint8_t>((size_t)s.B * 768);
+    b.fin_code = c.take<uint8_t>((size_t)s.B * 768);
+    b.fin_val = c.take<float>((size_t)s.B * 768);
+    b.tile_lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
+    b.lab = c.take<uint8_t>(n3);
+    b.codes = c.take<uint8_t>(n3);
+    return b;
+}
+
+}  // namespace
+
+size_t codes_ws_bytes(Shape s, int tx, int ty)
+{
+    Carver c(nullptr);
+    carve_codes(c, s, tx, ty);
+    return c.total();
+}
+
+// The five strategies that live in the code domain.  `f64` selects the ES arithmetic (float64 after the first
+// u8 quantisation, eps 1e-10, gamma = clip(x**(1/g))); otherwise S6 arithmetic (float32, eps 1e-6, x**g).
+int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st)
+{
+    Carver c(ws);
+    const int tx = p->tiles_x, ty = p->tiles_y;
+    CodeBufs B = carve_codes(c, s, tx, ty);
+    const long long n = (long long)s.npx();
+    const bool es = p->surface == UWIE_SURFACE_DICT;
+    const int k = p->strategy;
+    const dim3 gpx(grid_for(s.npx(), 1024), s.B), blk(256);
+    const ClaheGeom g = make_geom(s, p->clip_limit, tx, ty);
+    const double wb = p->wb_percentile;
+
+    UWIE_HIP_CHECK(hipMemsetAsync(B.hist_in, 0, sizeof(uint32_t) * (size_t)s.B * 768, st));
+    UWIE_HIP_CHECK(hipMemsetAsync(B.hist_mid, 0, sizeof(uint32_t) * (size_t)s.B * 768, st));
+    UWIE_LAUNCH(k_frame_hist, gpx, blk, 0, st, d_in, (int)n, B.hist_in);
+    UWIE_LAUNCH_CHECK();
+
+    ChainProg pre{}, post{};
+    pre.eps = post.eps = es ? 1e-10 : (double)1e-6f;
+    bool clahe = true, post_needs_hist = false;
+    ChainOp gam = simple_op(OP_GAMMA, es ? 2 : 1, es ? 1.0 / p->gamma : (double)(float)p->gamma);
+    if (!es && k == 4) {  // S6:262-268  clahe -> stretch -> white_balance -> gamma
+        pre.ops[pre.nops++] = simple_op(OP_INITQUANT);
+        post.ops[post.nops++] = simple_op(OP_FROMCODE);
+        stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, false);
+        stretch_op(&post.ops[post.nops++], n, wb, 100 - wb, false);
+        post.ops[post.nops++] = gam;
+        post_needs_hist = true;
+    } else if (!es && k == 5) {  // S6:270-277  white_balance -> stretch -> clahe -> gamma
+        pre.ops[pre.nops++] = simple_op(OP_INIT);
+        stretch_op(&pre.ops[pre.nops++], n, wb, 100 - wb, false);
+        stretch_op(&pre.ops[pre.nops++], n, p->L_low, p->L_high, false);
+        pre.ops[pre.nops++] = simple_op(OP_QUANT);
+        post.ops[post.nops++] = simple_op(OP_FROMCODE);
+        post.ops[post.nops++] = gam;
+    } else if (!es && k == 6) {  // S6:279-285  stretch -> clahe -> gamma
+        pre.ops[pre.nops++] = simple_op(OP_INIT);
+        stretch_op(&pre.ops[pre.nops++], n, p->L_low, p->L_high, false);
+        pre.ops[pre.nops++] = simple_op(OP_QUANT);
+        post.ops[post.nops++] = simple_op(OP_FROMCODE);
+        post.ops[post.nops++] = gam;
+    } else if (es && k == UWIE_DICT_CLAHE_ENHANCEMENT) {  // ES:400-420
+        pre.ops[pre.nops++] = simple_op(OP_INITQUANT);
+        post.ops[post.nops++] = simple_op(OP_FROMCODE);
+        stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, true);
+        if (p->apply_gamma) post.ops[post.nops++] = gam;
+        post_needs_hist = true;
+    } else if (es && k == UWIE_DICT_HISTOGRAM_EQUALIZATION) {  // ES:461-474: everything is one LUT of the input frame
+        clahe = false;
+        post.ops[post.nops++] = simple_op(OP_INITQUANT);
+        post.ops[post.nops++] = simple_op(OP_EQUALIZE);
+        post.ops[post.nops++] = simple_op(OP_FROMCODE);
+        stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, true);
+        if (p->apply_gamma) post.ops[post.nops++] = gam;
+    } else {
+        set_error("strategy %d of surface %d is not a code-domain strategy", k, p->surface);
+        return UWIE_E_INVALID;
+    }
+    post.ops[post.nops++] = simple_op(OP_QUANT);
+
+    auto run_chain = [&](const ChainProg &prog, const uint32_t *hist, const int32_t *kind, uint8_t *lc, float *lv) -> int {
+        if (es) UWIE_LAUNCH(k_code_chain<double>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv);
+        else UWIE_LAUNCH(k_code_chain<float>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv);
+        UWIE_LAUNCH_CHECK();
+        return UWIE_OK;
+    };
+
+    if (!clahe) {
+        int rc = run_chain(post, B.hist_in, d_kind, B.fin_code, B.fin_val);
+        if (rc != UWIE_OK) return rc;
+        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, d_in, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32);
+        UWIE_LAUNCH_CHECK();
+        return UWIE_OK;
+    }
+    int rc = run_chain(pre, B.hist_in, d_kind, B.lut_a_code, nullptr);
+    if (rc != UWIE_OK) return rc;
+    UWIE_LAUNCH(k_codes_lab_lut, dim3(tx * ty, s.B), blk, 0, st, ctx->d_lab, d_in, B.lut_a_code, g, B.lab, B.tile_lut);
+    UWIE_LAUNCH_CHECK();
+    if (post_needs_hist) {
+        UWIE_LAUNCH(k_clahe_apply_codes, gpx, blk, 0, st, ctx->d_lab, B.lab, B.tile_lut, g, (const uint8_t *)nullptr,
+                    (const float *)nullptr, (uint8_t *)nullptr, (float *)nullptr, B.codes, B.hist_mid);
+        UWIE_LAUNCH_CHECK();
+        rc = run_chain(post, B.hist_mid, nullptr, B.fin_code, B.fin_val);
+        if (rc != UWIE_OK) return rc;
+        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, B.codes, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32);
+        UWIE_LAUNCH_CHECK();
+        return UWIE_OK;
+    }
+    // the post chain has no percentile: its LUT does not depend on the image, evaluate it on a flat histogram
+    rc = run_chain(post, B.hist_in, nullptr, B.fin_code, B.fin_val);
+    if (rc != UWIE_OK) return rc;
+    UWIE_LAUNCH(k_clahe_apply_codes, gpx, blk, 0, st, ctx->d_lab, B.lab, B.tile_lut, g, B.fin_code, B.fin_val, d_out_u8,
+                d_out_f32, (uint8_t *)nullptr, (uint32_t *)nullptr);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+}  // namespace uwie

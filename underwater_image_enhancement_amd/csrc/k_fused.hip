@@ -266,6 +266,64 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
     }
 }
 
+// ---- ES surface, float64
+// recovered = clip((img - A) / t + A, 0, 1): float32 difference, float64 quotient/sum/result (ES:247-248)
+__global__ void __launch_bounds__(256) k_recover64_planar_hist(const uint8_t *__restrict__ in, const float *__restrict__ A,
+                                                               const double *__restrict__ t, int npx,
+                                                               double *__restrict__ planar, uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t h[3][2048];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < 3 * 2048; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    double *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
+    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
+        const uint8_t *q = img + (size_t)p * 3;
+        const double tv = t[(size_t)b * npx + p];
+        const double r0 = fmin(fmax((double)(px_norm(q[0]) - a0) / tv + (double)a0, 0.0), 1.0);
+        const double r1 = fmin(fmax((double)(px_norm(q[1]) - a1) / tv + (double)a1, 0.0), 1.0);
+        const double r2 = fmin(fmax((double)(px_norm(q[2]) - a2) / tv + (double)a2, 0.0), 1.0);
+        o0[p] = r0;
+        o1[p] = r1;
+        o2[p] = r2;
+        atomicAdd(&h[0][(uint32_t)(f64_key(r0) >> 53)], 1u);
+        atomicAdd(&h[1][(uint32_t)(f64_key(r1) >> 53)], 1u);
+        atomicAdd(&h[2][(uint32_t)(f64_key(r2) >> 53)], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * 2048; i += 256) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / 2048) * kSelGroupStride + (i % 2048)], c);
+    }
+}
+
+// pct: [B][3][2] float64 = lo, hi.  grid (n, B)
+__global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict__ planar, const double *__restrict__ pct,
+                                                       int npx, int apply_gamma, double gexp,
+                                                       uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
+{
+    const int b = blockIdx.y;
+    double lo[3], den[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = pct[(b * 3 + c) * 2];
+        den[c] = (pct[(b * 3 + c) * 2 + 1] - lo[c]) + 1e-10;
+    }
+    const double *r = planar + (size_t)b * 3 * npx;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
+        const size_t o = ((size_t)b * npx + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double y = fmin(fmax((r[(size_t)c * npx + p] - lo[c]) / den[c], 0.0), 1.0);
+            if (apply_gamma) y = fmin(fmax(pow(y, gexp), 0.0), 1.0);
+            if (out_u8) out_u8[o + c] = (uint8_t)((int)(y * 255.0) & 0xff);
+            if (out_f32) out_f32[o + c] = (float)y;
+        }
+    }
+}
+
 ClaheGeom make_geom(Shape s, double clip, int tx, int ty)
 {
     ClaheGeom g;
@@ -300,6 +358,28 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     if (nblk > need) nblk = need;
     UWIE_LAUNCH(k_restore_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(), d_planar,
                 d_ghist);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
+                                 uint32_t *d_ghist, hipStream_t st)
+{
+    int nblk = 2048 / s.B;
+    nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
+    const int need = cdiv((long long)s.npx(), 256);
+    if (nblk > need) nblk = need;
+    UWIE_LAUNCH(k_recover64_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar,
+                d_ghist);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
+                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st)
+{
+    UWIE_LAUNCH(k_stretch64_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, d_planar, d_pct, (int)s.npx(),
+                apply_gamma, 1.0 / gamma, d_out_u8, d_out_f32);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
