@@ -73,6 +73,9 @@ typedef struct uwie_params {
     int32_t tiles_x, tiles_y; /* CLAHE tile grid (S6: 8x8 fixed; ES: tile_grid_size)             */
     double gamma;          /* S6:222 exponent g (x**g); ES:276 g (clip(x**(1/g)))                */
     int32_t apply_gamma;   /* 0/1 (ES `apply_gamma`; S6 strategies 1,4,5,6 always 1)             */
+    int32_t gf_exact;      /* guided filter: 1 = reproduce cv2.boxFilter's float64 running-sum order bit for
+                              bit (6 materialised planes); 0 (default) = fused single-kernel float64 filter,
+                              same window/border, free summation order: |t - t_exact| <= 1e-11            */
 } uwie_params;
 
 const char *uwie_last_error(void);
@@ -136,7 +139,7 @@ int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int b
 
 /* guided_filter(gray/255, t0, r, eps) followed by clip(.,0.1,1) (S6:178-180, ES:229-232): float64 [batch][H][W]. */
 int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
-                       double eps, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
+                       double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* restore_image (S6:183-188): float32 [batch][H][W][3]. */
 int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t,

@@ -134,3 +134,14 @@ def test_dict_surface_error_behaviour(uw, orc):
         uw.EnhancementStrategies.apply_strategy(x, "weak_dehazing", {})  # commented out in the reference (ES:494-496)
     bad = rng.random((16, 16, 3)).astype(np.float32)  # not u8-derived: swallowed, input returned (ES:503-508)
     assert uw.EnhancementStrategies.apply_strategy(bad, "strong_dehazing", {}) is bad
+
+
+@pytest.mark.parametrize("strategy", [1, 2, 3])
+def test_exact_order_guided_filter_mode(uw, orc, strategy):
+    """gf_exact=1 (cv2.boxFilter's running-sum order) and the default fused filter give the same u8 image here."""
+    frames = frames_for_tests(np.random.default_rng(4242))
+    for name in ("green_120x160", "hazy_97x131", "noise_61x83"):
+        u8 = frames[name]
+        want = orc.enhance_u8(u8, strategy)
+        assert np.array_equal(uw.enhance(u8, strategy=strategy, gf_exact=1), want)
+        assert check_u8(uw.enhance(u8, strategy=strategy, gf_exact=0), want, name) == 0

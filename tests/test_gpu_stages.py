@@ -192,8 +192,12 @@ def test_transmission_init_and_guided_filter(dev, orc, frames):
             want_gray = orc.cv_rgb2gray_u8((xc * 255).astype(np.uint8))
             same(t0[0].cpu().numpy(), want_t0)
             same(gray[0].cpu().numpy(), want_gray)
-            t = dev.guided_filter(gray, t0, ks, eps)
-            same(t[0].cpu().numpy(), S6.transmission(xc, A, omega, ks, eps))
+            want_t = S6.transmission(xc, A, omega, ks, eps)
+            t = dev.guided_filter(gray, t0, ks, eps, exact=True)  # cv2.boxFilter's running-sum order, bit for bit
+            same(t[0].cpu().numpy(), want_t)
+            # default fused filter: same windows and borders, free float64 summation order.  Tolerance: 1e-11 absolute
+            tf = dev.guided_filter(gray, t0, ks, eps, exact=False)[0].cpu().numpy()
+            assert tf.dtype == np.float64 and np.abs(tf - want_t).max() <= 1e-11, (name, ks, np.abs(tf - want_t).max())
 
 
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)

@@ -45,6 +45,7 @@ class UwieParams(ctypes.Structure):
         ("tiles_y", ctypes.c_int32),
         ("gamma", ctypes.c_double),
         ("apply_gamma", ctypes.c_int32),
+        ("gf_exact", ctypes.c_int32),
     ]
 
 
@@ -67,7 +68,7 @@ SIGNATURES = {
     "uwie_atmospheric_light": [_VP, _VP, _VP, _I, _I, _I, _PP, _VP, _VP, _VP, _SZ, _VP],
     "uwie_transmission_init": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _VP, _VP],
     "uwie_box_filter_f64": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _SZ, _VP],
-    "uwie_guided_filter": [_VP, _VP, _VP, _I, _I, _I, _I, _D, _VP, _VP, _SZ, _VP],
+    "uwie_guided_filter": [_VP, _VP, _VP, _I, _I, _I, _I, _D, _I, _VP, _VP, _SZ, _VP],
     "uwie_restore": [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP],
     "uwie_percentiles_f32": [_VP, _VP, _I, _I, _I, ctypes.POINTER(_D), _I, _VP, _VP, _SZ, _VP],
     "uwie_stretch_f32": [_VP, _VP, _VP, _I, _I, _I, _D, _D, _VP, _SZ, _VP],

@@ -101,6 +101,14 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     return P;
 }
 
+int stage_guided(const Pipe &P, Shape s, const uwie_params *p, hipStream_t st)
+{
+    int handled = 0;
+    if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st));
+    if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+    return UWIE_OK;
+}
+
 int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipStream_t st)
 {
     const double q[2] = {lo, hi};
@@ -126,7 +134,7 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
         UWIE_TRY(launch_quant_gray(d_in, kind, P.gray, s, p->gray_shift, st));
         UWIE_TRY(launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
         UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
-        UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+        UWIE_TRY(stage_guided(P, s, p, st));
         // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
         SelectPlan plan;
         const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
@@ -152,7 +160,7 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
     UWIE_TRY(launch_quant_gray(d_in, nullptr, P.gray, s, p->gray_shift, st));
     UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
     UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
-    UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+    UWIE_TRY(stage_guided(P, s, p, st));
     SelectPlan plan;
     const double q[2] = {p->L_low, p->L_high};
     UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
@@ -390,13 +398,16 @@ int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int b
 }
 
 int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
-                       double eps, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream)
+                       double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_gray && d_t0 && d_t, "guided_filter: NULL pointer");
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "guided_filter: ksize out of range");
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(guided_ws_bytes(s));
+    int handled = 0;
+    if (!exact) UWIE_TRY(launch_guided_fast(d_gray, d_t0, s, ksize, eps, d_t, &handled, (hipStream_t)stream));
+    if (handled) return UWIE_OK;
     return launch_guided(d_gray, d_t0, s, ksize, eps, d_t, d_workspace, (hipStream_t)stream);
 }
 

@@ -160,11 +160,11 @@ class Device:
                                            self.stream()))
         return out
 
-    def guided_filter(self, gray, t0, ksize, eps):
+    def guided_filter(self, gray, t0, ksize, eps, exact=True):
         B, H, W = (int(v) for v in gray.shape)
         ws = self.workspace_for(B, H, W)
         t = self.empty((B, H, W), torch.float64)
-        check(self.lib.uwie_guided_filter(self._ctx, _ptr(gray), _ptr(t0), B, H, W, int(ksize), float(eps), _ptr(t),
+        check(self.lib.uwie_guided_filter(self._ctx, _ptr(gray), _ptr(t0), B, H, W, int(ksize), float(eps), int(exact), _ptr(t),
                                           _ptr(ws), ws.numel(), self.stream()))
         return t
 
