@@ -5,8 +5,8 @@
 // entry point uses one region per frame.
 //
 // Stages (all integer arithmetic, bit-exact by construction):
-//   k_canny_grad   3x3 Sobel with BORDER_REPLICATE at the region edge -> |dx|+|dy| and the NMS direction class
-//   k_canny_nms    non-maximum suppression with OpenCV's fixed-point tan(22.5 deg) -> map {weak, none, strong}
+//   k_canny_gradnms  16x64 tiles through LDS: 3x3 Sobel with BORDER_REPLICATE at the region edge -> |dx|+|dy| and the
+//                  direction class; non-maximum suppression with OpenCV's fixed-point tan(22.5 deg) -> map {weak, none, strong}
 //   k_canny_union  8-connected components of (weak | strong) pixels: lock-free union-find on pixel indices
 //                  (links always point to the smaller index; agent-scope atomics, so XCD placement is irrelevant)
 //   k_canny_flat   pointer jumping: every candidate points at its root
@@ -36,54 +36,84 @@ __device__ __forceinline__ bool region_px(const Region &r, int lp, int &y, int &
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_canny_grad(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
-                                                    int H, int W, uint16_t *__restrict__ magdir)
+// Sobel + direction class + non-maximum suppression for one 16x64 tile of a region, staged through LDS:
+// gray tile with a 2-pixel halo (replicated at the REGION border, like Sobel's BORDER_REPLICATE on the quadrant),
+// magnitude tile with a 1-pixel halo (0 outside the region, like OpenCV's zero-padded magnitude rows/columns).
+// Writes the map byte of every pixel, and label/flag only for candidates (nobody reads them elsewhere).
+constexpr int kCT_H = 16, kCT_W = 64;
+
+__global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
+                                                       int H, int W, int tiles_x, int low, int high, CannyBufs bufs)
 {
+    __shared__ uint8_t sg[kCT_H + 4][kCT_W + 4];
+    __shared__ uint16_t sm[kCT_H + 2][kCT_W + 2];
     const Region r = regs[blockIdx.y];
-    int y, x;
-    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
-    const uint8_t *g = gray + (size_t)r.img * H * W;
-    const int ym = max(y - 1, r.y0), yp = min(y + 1, r.y0 + r.rows - 1);
-    const int xm = max(x - 1, r.x0), xp = min(x + 1, r.x0 + r.cols - 1);
-    const int a = g[(size_t)ym * W + xm], b = g[(size_t)ym * W + x], c = g[(size_t)ym * W + xp];
-    const int d = g[(size_t)y * W + xm], f = g[(size_t)y * W + xp];
-    const int p = g[(size_t)yp * W + xm], q = g[(size_t)yp * W + x], s = g[(size_t)yp * W + xp];
-    const int dx = (c - a) + 2 * (f - d) + (s - p);
-    const int dy = (p - a) + 2 * (q - b) + (s - c);
-    const int ax = abs(dx), ay = abs(dy) << 15;
-    const int tg22x = ax * 13573;  // (int)(tan(22.5deg) * 2^15 + 0.5)
-    int dir;
-    if (ay < tg22x) dir = 0;
-    else if (ay > tg22x + (ax << 16)) dir = 1;
-    else dir = ((dx ^ dy) < 0) ? 3 : 2;
-    magdir[(size_t)r.img * H * W + (size_t)y * W + x] = (uint16_t)((abs(dx) + abs(dy)) | (dir << 12));
+    const int ty0 = (blockIdx.x / tiles_x) * kCT_H, tx0 = (blockIdx.x % tiles_x) * kCT_W;  // tile origin inside the region
+    if (ty0 >= r.rows || tx0 >= r.cols) return;
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)r.img * H * W;
+    const uint8_t *g = gray + base;
+    for (int i = tid; i < (kCT_H + 4) * (kCT_W + 4); i += 256) {
+        const int ly = i / (kCT_W + 4), lx = i % (kCT_W + 4);
+        const int ry = min(max(ty0 + ly - 2, 0), r.rows - 1), rx = min(max(tx0 + lx - 2, 0), r.cols - 1);
+        sg[ly][lx] = g[(size_t)(r.y0 + ry) * W + r.x0 + rx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kCT_H + 2) * (kCT_W + 2); i += 256) {
+        const int ly = i / (kCT_W + 2), lx = i % (kCT_W + 2);
+        const int ry = ty0 + ly - 1, rx = tx0 + lx - 1;  // region coordinates of this magnitude sample
+        uint16_t v = 0;
+        if (ry >= 0 && ry < r.rows && rx >= 0 && rx < r.cols) {
+            const int a = sg[ly][lx], b = sg[ly][lx + 1], c = sg[ly][lx + 2];
+            const int d = sg[ly + 1][lx], f = sg[ly + 1][lx + 2];
+            const int p = sg[ly + 2][lx], q = sg[ly + 2][lx + 1], s = sg[ly + 2][lx + 2];
+            const int dx = (c - a) + 2 * (f - d) + (s - p);
+            const int dy = (p - a) + 2 * (q - b) + (s - c);
+            const int ax = abs(dx), ay = abs(dy) << 15;
+            const int tg22x = ax * 13573;  // (int)(tan(22.5deg) * 2^15 + 0.5)
+            int dir;
+            if (ay < tg22x) dir = 0;
+            else if (ay > tg22x + (ax << 16)) dir = 1;
+            else dir = ((dx ^ dy) < 0) ? 3 : 2;
+            v = (uint16_t)((abs(dx) + abs(dy)) | (dir << 12));
+        }
+        sm[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < kCT_H * kCT_W; i += 256) {
+        const int ly = i / kCT_W, lx = i % kCT_W;
+        const int ry = ty0 + ly, rx = tx0 + lx;
+        if (ry >= r.rows || rx >= r.cols) continue;
+        const int v = sm[ly + 1][lx + 1];
+        const int m = v & 0xfff, dir = v >> 12;
+        auto M = [&](int dy, int dx) -> int { return sm[ly + 1 + dy][lx + 1 + dx] & 0xfff; };
+        bool keep = false;
+        if (m > low) {
+            if (dir == 0) keep = m > M(0, -1) && m >= M(0, 1);
+            else if (dir == 1) keep = m > M(-1, 0) && m >= M(1, 0);
+            else if (dir == 2) keep = m > M(-1, -1) && m > M(1, 1);
+            else keep = m > M(-1, 1) && m > M(1, -1);
+        }
+        const int p = (r.y0 + ry) * W + r.x0 + rx;
+        bufs.cmap[base + p] = keep ? (m > high ? 2 : 0) : 1;
+        if (keep) {
+            bufs.label[base + p] = p;
+            bufs.flag[base + p] = 0;
+        }
+    }
 }
 
-__global__ void __launch_bounds__(256) k_canny_nms(const Region *__restrict__ regs, int H, int W, int low, int high,
-                                                   CannyBufs bufs)
+// The component kernels walk a region four pixels of a row per thread and skip groups without candidates
+// (map byte 1), which is almost every group on smooth frames.
+__device__ __forceinline__ bool region_quad(const Region &r, int lq, int &y, int &x, int &n)
 {
-    const Region r = regs[blockIdx.y];
-    int y, x;
-    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
-    const size_t base = (size_t)r.img * H * W;
-    const uint16_t *md = bufs.magdir + base;
-    auto M = [&](int yy, int xx) -> int {
-        if (yy < r.y0 || yy >= r.y0 + r.rows || xx < r.x0 || xx >= r.x0 + r.cols) return 0;
-        return md[(size_t)yy * W + xx] & 0xfff;
-    };
-    const int v = md[(size_t)y * W + x];
-    const int m = v & 0xfff, dir = v >> 12;
-    bool keep = false;
-    if (m > low) {
-        if (dir == 0) keep = m > M(y, x - 1) && m >= M(y, x + 1);
-        else if (dir == 1) keep = m > M(y - 1, x) && m >= M(y + 1, x);
-        else if (dir == 2) keep = m > M(y - 1, x - 1) && m > M(y + 1, x + 1);
-        else keep = m > M(y - 1, x + 1) && m > M(y + 1, x - 1);
-    }
-    const int p = y * W + x;
-    bufs.cmap[base + p] = keep ? (m > high ? 2 : 0) : 1;
-    bufs.label[base + p] = keep ? p : -1;
-    bufs.flag[base + p] = 0;
+    const int qpr = (r.cols + 3) / 4;
+    if (lq >= r.rows * qpr) return false;
+    y = r.y0 + lq / qpr;
+    const int lx = (lq % qpr) * 4;
+    x = r.x0 + lx;
+    n = min(4, r.cols - lx);
+    return true;
 }
 
 __device__ __forceinline__ int ld_label(const int32_t *L, int i)
@@ -120,73 +150,86 @@ __device__ void uf_union(int32_t *L, int a, int b)
 __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     const Region r = regs[blockIdx.y];
-    int y, x;
-    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    int y, x0, n;
+    if (!region_quad(r, blockIdx.x * 256 + threadIdx.x, y, x0, n)) return;
     const size_t base = (size_t)r.img * H * W;
     const uint8_t *cm = bufs.cmap + base;
     int32_t *L = bufs.label + base;
-    const int p = y * W + x;
-    if (cm[p] == 1) return;
-    const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
-    if (right && cm[p + 1] != 1) uf_union(L, p, p + 1);
-    if (down) {
-        if (left && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
-        if (cm[p + W] != 1) uf_union(L, p, p + W);
-        if (right && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
+    const bool down = y + 1 < r.y0 + r.rows;
+    for (int i = 0; i < n; ++i) {
+        const int x = x0 + i, p = y * W + x;
+        if (cm[p] == 1) continue;
+        const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0;
+        if (right && cm[p + 1] != 1) uf_union(L, p, p + 1);
+        if (down) {
+            if (left && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
+            if (cm[p + W] != 1) uf_union(L, p, p + W);
+            if (right && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) k_canny_flat(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     const Region r = regs[blockIdx.y];
-    int y, x;
-    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
-    int32_t *L = bufs.label + (size_t)r.img * H * W;
-    const int p = y * W + x;
-    if (ld_label(L, p) < 0) return;
-    int root = p;
-    for (;;) {
-        const int q = ld_label(L, root);
-        if (q == root) break;
-        root = q;
+    int y, x0, n;
+    if (!region_quad(r, blockIdx.x * 256 + threadIdx.x, y, x0, n)) return;
+    const size_t base = (size_t)r.img * H * W;
+    const uint8_t *cm = bufs.cmap + base;
+    int32_t *L = bufs.label + base;
+    for (int i = 0; i < n; ++i) {
+        const int p = y * W + x0 + i;
+        if (cm[p] == 1) continue;
+        int root = p;
+        for (;;) {
+            const int q = ld_label(L, root);
+            if (q == root) break;
+            root = q;
+        }
+        if (root != p) atomicMin(L + p, root);
     }
-    if (root != p) atomicMin(L + p, root);
 }
 
 __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     const Region r = regs[blockIdx.y];
-    int y, x;
-    if (!region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) return;
+    int y, x0, n;
+    if (!region_quad(r, blockIdx.x * 256 + threadIdx.x, y, x0, n)) return;
     const size_t base = (size_t)r.img * H * W;
-    const int p = y * W + x;
-    if (bufs.cmap[base + p] != 2) return;
     const int32_t *L = bufs.label + base;
-    int root = p;
-    while (L[root] != root) root = L[root];
-    bufs.flag[base + root] = 1;
+    for (int i = 0; i < n; ++i) {
+        const int p = y * W + x0 + i;
+        if (bufs.cmap[base + p] != 2) continue;
+        int root = p;
+        while (L[root] != root) root = L[root];
+        bufs.flag[base + root] = 1;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
                                                     uint32_t *__restrict__ count, uint8_t *__restrict__ edges)
 {
     const Region r = regs[blockIdx.y];
-    int y, x;
-    bool edge = false;
-    if (region_px(r, blockIdx.x * 256 + threadIdx.x, y, x)) {
+    int y, x0, n;
+    uint32_t mine = 0;
+    if (region_quad(r, blockIdx.x * 256 + threadIdx.x, y, x0, n)) {
         const size_t base = (size_t)r.img * H * W;
-        const int p = y * W + x;
         const int32_t *L = bufs.label + base;
-        if (L[p] >= 0) {
-            int root = p;
-            while (L[root] != root) root = L[root];
-            edge = bufs.flag[base + root] != 0;
+        for (int i = 0; i < n; ++i) {
+            const int p = y * W + x0 + i;
+            bool edge = false;
+            if (bufs.cmap[base + p] != 1) {
+                int root = p;
+                while (L[root] != root) root = L[root];
+                edge = bufs.flag[base + root] != 0;
+            }
+            if (edges) edges[base + p] = edge ? 255 : 0;
+            mine += edge;
         }
-        if (edges) edges[base + p] = edge ? 255 : 0;
     }
     if (count) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(edge));
-        if ((threadIdx.x & 63) == 0 && n) atomicAdd(count + blockIdx.y, n);
+        const uint32_t tot = wave_sum_u32(mine);
+        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + blockIdx.y, tot);
     }
 }
 
@@ -228,11 +271,11 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
 {
     Carver c(ws);
     CannyBufs bufs = carve_canny(c, s);
-    const dim3 grid(cdiv((long long)max_rows * max_cols, 256), nreg), block(256);
+    const int tiles_x = cdiv(max_cols, kCT_W), tiles_y = cdiv(max_rows, kCT_H);
+    const dim3 tgrid(tiles_x * tiles_y, nreg), block(256);
+    const dim3 grid(cdiv((long long)max_rows * cdiv(max_cols, 4), 256), nreg);
     if (d_count) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
-    UWIE_LAUNCH(k_canny_grad, grid, block, 0, st, d_gray, d_regions, s.H, s.W, bufs.magdir);
-    UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_canny_nms, grid, block, 0, st, d_regions, s.H, s.W, low, high, bufs);
+    UWIE_LAUNCH(k_canny_gradnms, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_canny_union, grid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
