@@ -17,6 +17,50 @@ __device__ __forceinline__ float px_val(uint32_t u, bool attenuate)
     float x = (float)u / 255.0f;
     return attenuate ? x * 0.85f : x;
 }
+// Four consecutive RGB pixels (12 bytes).  Frames whose pixel count is a multiple of 4 keep every 4-pixel group
+// 4-byte aligned (frame bases are multiples of 12 bytes from a 256-byte aligned allocation), so the group comes in
+// as three dwords; other frames fall back to byte loads.
+struct Px4 {
+    uint32_t r[4], g[4], b[4];
+};
+__device__ __forceinline__ Px4 load_px4(const uint8_t *p, int n, bool aligned)
+{
+    Px4 o;
+    if (aligned && n == 4) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];  // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+        o.r[0] = w0 & 255; o.g[0] = (w0 >> 8) & 255; o.b[0] = (w0 >> 16) & 255;
+        o.r[1] = w0 >> 24; o.g[1] = w1 & 255; o.b[1] = (w1 >> 8) & 255;
+        o.r[2] = (w1 >> 16) & 255; o.g[2] = w1 >> 24; o.b[2] = w2 & 255;
+        o.r[3] = (w2 >> 8) & 255; o.g[3] = (w2 >> 16) & 255; o.b[3] = w2 >> 24;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = i < n;
+            o.r[i] = ok ? p[3 * i] : 0;
+            o.g[i] = ok ? p[3 * i + 1] : 0;
+            o.b[i] = ok ? p[3 * i + 2] : 0;
+        }
+    }
+    return o;
+}
+__device__ __forceinline__ void store_px4(uint8_t *p, const uint32_t *r, const uint32_t *g, const uint32_t *b, int n,
+                                          bool aligned)
+{
+    if (aligned && n == 4) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(p);
+        w[0] = r[0] | (g[0] << 8) | (b[0] << 16) | (r[1] << 24);
+        w[1] = g[1] | (b[1] << 8) | (r[2] << 16) | (g[2] << 24);
+        w[2] = b[2] | (r[3] << 8) | (g[3] << 16) | (b[3] << 24);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            p[3 * i] = (uint8_t)r[i];
+            p[3 * i + 1] = (uint8_t)g[i];
+            p[3 * i + 2] = (uint8_t)b[i];
+        }
+    }
+}
+
 // which channel color_correction attenuates for a cast kind (UWIE_CAST_*): greenish -> G, bluish -> B
 __device__ __forceinline__ bool px_atten(int kind, int c) { return kind != 0 && c == kind; }
 // (img * 255).astype(np.uint8): float32 product, truncation toward zero

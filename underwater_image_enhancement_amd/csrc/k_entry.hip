@@ -30,11 +30,17 @@ __global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ 
     __syncthreads();
     const uint8_t *img = in + (size_t)b * npx * 3;
     const int p0 = c * kChunkPx, p1 = min(npx, p0 + kChunkPx);
-    for (int p = p0 + tid; p < p1; p += 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        atomicAdd(&h[w][q[0]], 1u);
-        atomicAdd(&h[w][256 + q[1]], 1u);
-        atomicAdd(&h[w][512 + q[2]], 1u);
+    const bool aligned = (npx & 3) == 0;
+    for (int p = p0 + tid * 4; p < p1; p += 1024) {
+        const int n = min(4, p1 - p);
+        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) {
+                atomicAdd(&h[w][v.r[i]], 1u);
+                atomicAdd(&h[w][256 + v.g[i]], 1u);
+                atomicAdd(&h[w][512 + v.b[i]], 1u);
+            }
     }
     __syncthreads();
     uint32_t *out = hist + ((size_t)b * nchunk + c) * 768;
@@ -212,19 +218,28 @@ __global__ void __launch_bounds__(256) k_quant_gray(const uint8_t *__restrict__ 
     const int k = kind ? kind[b] : 0;
     const uint8_t *img = in + (size_t)b * npx * 3;
     uint8_t *g = gray + (size_t)b * npx;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        const uint32_t r = quant_u8(px_val(q[0], false));
-        const uint32_t gg = quant_u8(px_val(q[1], px_atten(k, 1)));
-        const uint32_t bb = quant_u8(px_val(q[2], px_atten(k, 2)));
-        g[p] = (uint8_t)gray_fixed(r, gg, bb, shift);
+    const bool aligned = (npx & 3) == 0;
+    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = gray_fixed(quant_u8(px_val(v.r[i], false)), quant_u8(px_val(v.g[i], ag)), quant_u8(px_val(v.b[i], ab)),
+                              shift);
+        if (aligned && n == 4) {
+            *reinterpret_cast<uint32_t *>(g + p) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        } else {
+            for (int i = 0; i < n; ++i) g[p + i] = (uint8_t)o[i];
+        }
     }
 }
 
 int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int gray_shift,
                       hipStream_t st)
 {
-    const int blocks = grid_for(s.npx(), 4096);
+    const int blocks = grid_for((s.npx() + 3) / 4, 4096);
     UWIE_LAUNCH(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_gray, (int)s.npx(), gray_shift);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;

@@ -33,21 +33,45 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
     const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
     const uint8_t *img = in + (size_t)b * npx * 3;
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
-    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        const double tv = t[(size_t)b * npx + p];
-        const float d0 = px_val(q[0], false) - a0;
-        const float d1 = px_val(q[1], px_atten(k, 1)) - a1;
-        const float d2 = px_val(q[2], px_atten(k, 2)) - a2;
-        const float r0 = clip01((float)((double)d0 / tv + (double)a0));
-        const float r1 = clip01((float)((double)d1 / tv + (double)a1));
-        const float r2 = clip01((float)((double)d2 / tv + (double)a2));
-        o0[p] = r0;
-        o1[p] = r1;
-        o2[p] = r2;
-        atomicAdd(&h[0][f32_key(r0) >> 21], 1u);
-        atomicAdd(&h[1][f32_key(r1) >> 21], 1u);
-        atomicAdd(&h[2][f32_key(r2) >> 21], 1u);
+    const bool aligned = (npx & 3) == 0;
+    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
+    const double *trow = t + (size_t)b * npx;
+    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
+        double tv[4];
+        if (aligned && n == 4) {
+            const double2 ta = *reinterpret_cast<const double2 *>(trow + p), tb = *reinterpret_cast<const double2 *>(trow + p + 2);
+            tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
+        } else {
+            for (int i = 0; i < 4; ++i) tv[i] = i < n ? trow[p + i] : 1.0;
+        }
+        float r0[4], r1[4], r2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d0 = px_val(v.r[i], false) - a0;
+            const float d1 = px_val(v.g[i], ag) - a1;
+            const float d2 = px_val(v.b[i], ab) - a2;
+            r0[i] = clip01((float)((double)d0 / tv[i] + (double)a0));
+            r1[i] = clip01((float)((double)d1 / tv[i] + (double)a1));
+            r2[i] = clip01((float)((double)d2 / tv[i] + (double)a2));
+            if (i < n) {
+                atomicAdd(&h[0][f32_key(r0[i]) >> 21], 1u);
+                atomicAdd(&h[1][f32_key(r1[i]) >> 21], 1u);
+                atomicAdd(&h[2][f32_key(r2[i]) >> 21], 1u);
+            }
+        }
+        if (aligned && n == 4) {
+            *reinterpret_cast<float4 *>(o0 + p) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+            *reinterpret_cast<float4 *>(o1 + p) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            *reinterpret_cast<float4 *>(o2 + p) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+        } else {
+            for (int i = 0; i < n; ++i) {
+                o0[p + i] = r0[i];
+                o1[p + i] = r1[i];
+                o2[p + i] = r2[i];
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < 3 * 2048; i += 256) {
@@ -201,45 +225,59 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
     const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
     constexpr int BASE = 1 << 14;
-    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
-        const int y = p / g.W, x = p % g.W;
-        const float tyf = (float)y * inv_th - 0.5f;
-        int ty1 = (int)floorf(tyf);
-        int ty2 = ty1 + 1;
-        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
-        ty1 = max(ty1, 0);
-        ty2 = min(ty2, g.ty - 1);
-        const float txf = (float)x * inv_tw - 0.5f;
-        int tx1 = (int)floorf(txf);
-        int tx2 = tx1 + 1;
-        const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
-        tx1 = max(tx1, 0);
-        tx2 = min(tx2, g.tx - 1);
-        const uint8_t *q = lab + ((size_t)b * npx + p) * 3;
-        const int v = q[0], aa = q[1], bb = q[2];
-        const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
-        const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
-        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
-        const int LL = sat_u8(__float2int_rn(res));
-        // LAB2RGB (Lab2RGBinteger)
-        const int yy = s_ltoyf[LL * 2], ify = s_ltoyf[LL * 2 + 1];
-        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
-        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
-        const int xx = ab_to_xz(ify + adiv), zz = ab_to_xz(ify - bdiv);
-        const int ro = min(max(UWIE_DESCALE(s_inv[0] * xx + s_inv[1] * yy + s_inv[2] * zz, 14), 0), 4095);
-        const int go = min(max(UWIE_DESCALE(s_inv[3] * xx + s_inv[4] * yy + s_inv[5] * zz, 14), 0), 4095);
-        const int bo = min(max(UWIE_DESCALE(s_inv[6] * xx + s_inv[7] * yy + s_inv[8] * zz, 14), 0), 4095);
-        const int c0 = s_invgamma[ro], c1 = s_invgamma[go], c2 = s_invgamma[bo];
-        const size_t o = ((size_t)b * npx + p) * 3;
-        if (out_u8) {
-            out_u8[o] = s_fu[c0];
-            out_u8[o + 1] = s_fu[c1];
-            out_u8[o + 2] = s_fu[c2];
+    const bool aligned = (npx & 3) == 0;
+    for (int p0 = (blockIdx.x * 256 + tid) * 4; p0 < npx; p0 += gridDim.x * 1024) {
+        const int n = min(4, npx - p0);
+        const Px4 in4 = load_px4(lab + ((size_t)b * npx + p0) * 3, n, aligned);  // r,g,b fields hold L,a,b
+        uint32_t o0[4], o1[4], o2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = min(p0 + i, npx - 1);
+            const int y = p / g.W, x = p % g.W;
+            const float tyf = (float)y * inv_th - 0.5f;
+            int ty1 = (int)floorf(tyf);
+            int ty2 = ty1 + 1;
+            const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+            ty1 = max(ty1, 0);
+            ty2 = min(ty2, g.ty - 1);
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf);
+            int tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            tx1 = max(tx1, 0);
+            tx2 = min(tx2, g.tx - 1);
+            const int v = in4.r[i], aa = in4.g[i], bb = in4.b[i];
+            const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
+            const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
+            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            const int LL = sat_u8(__float2int_rn(res));
+            // LAB2RGB (Lab2RGBinteger)
+            const int yy = s_ltoyf[LL * 2], ify = s_ltoyf[LL * 2 + 1];
+            const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+            const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+            const int xx = ab_to_xz(ify + adiv), zz = ab_to_xz(ify - bdiv);
+            const int ro = min(max(UWIE_DESCALE(s_inv[0] * xx + s_inv[1] * yy + s_inv[2] * zz, 14), 0), 4095);
+            const int go = min(max(UWIE_DESCALE(s_inv[3] * xx + s_inv[4] * yy + s_inv[5] * zz, 14), 0), 4095);
+            const int bo = min(max(UWIE_DESCALE(s_inv[6] * xx + s_inv[7] * yy + s_inv[8] * zz, 14), 0), 4095);
+            o0[i] = s_invgamma[ro];
+            o1[i] = s_invgamma[go];
+            o2[i] = s_invgamma[bo];
         }
-        if (out_f32) {
-            out_f32[o] = s_ff[c0];
-            out_f32[o + 1] = s_ff[c1];
-            out_f32[o + 2] = s_ff[c2];
+        const size_t o = ((size_t)b * npx + p0) * 3;
+        if (out_f32)
+            for (int i = 0; i < n; ++i) {
+                out_f32[o + 3 * i] = s_ff[o0[i]];
+                out_f32[o + 3 * i + 1] = s_ff[o1[i]];
+                out_f32[o + 3 * i + 2] = s_ff[o2[i]];
+            }
+        if (out_u8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0[i] = s_fu[o0[i]];
+                o1[i] = s_fu[o1[i]];
+                o2[i] = s_fu[o2[i]];
+            }
+            store_px4(out_u8 + o, o0, o1, o2, n, aligned);
         }
     }
 }
@@ -354,7 +392,7 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 {
     int nblk = 2048 / s.B;
     nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
-    const int need = cdiv((long long)s.npx(), 256);
+    const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     UWIE_LAUNCH(k_restore_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(), d_planar,
                 d_ghist);
@@ -403,7 +441,7 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     UWIE_LAUNCH(k_stretch_lab_lut, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, d_pct, pct_stride, eps, two,
                 g, lab, lut);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_clahe_apply_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g,
+    UWIE_LAUNCH(k_clahe_apply_out, dim3(grid_for((s.npx() + 3) / 4, 2048), s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g,
                 gamma_mode, gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;

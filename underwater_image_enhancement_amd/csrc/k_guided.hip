@@ -189,15 +189,28 @@ __global__ void __launch_bounds__(256) k_trans_init(const uint8_t *__restrict__ 
     const int k = kind ? kind[b] : 0;
     const float d0 = A[b * 3 + 0] + norm_eps, d1 = A[b * 3 + 1] + norm_eps, d2 = A[b * 3 + 2] + norm_eps;
     const uint8_t *img = in + (size_t)b * npx * 3;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        const float n0 = px_val(q[0], false) / d0;
-        const float n1 = px_val(q[1], px_atten(k, 1)) / d1;
-        const float n2 = px_val(q[2], px_atten(k, 2)) / d2;
-        const float dark = fminf(fminf(n0, n1), n2);
-        float t = 1.0f - omega * dark;
-        if (pre_clip) t = fminf(fmaxf(t, 0.1f), 1.0f);
-        t0[(size_t)b * npx + p] = t;
+    const bool aligned = (npx & 3) == 0;
+    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
+    float *trow = t0 + (size_t)b * npx;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n0 = px_val(v.r[i], false) / d0;
+            const float n1 = px_val(v.g[i], ag) / d1;
+            const float n2 = px_val(v.b[i], ab) / d2;
+            const float dark = fminf(fminf(n0, n1), n2);
+            float t = 1.0f - omega * dark;
+            if (pre_clip) t = fminf(fmaxf(t, 0.1f), 1.0f);
+            o[i] = t;
+        }
+        if (aligned && n == 4) {
+            *reinterpret_cast<float4 *>(trow + p) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int i = 0; i < n; ++i) trow[p + i] = o[i];
+        }
     }
 }
 
@@ -206,7 +219,7 @@ __global__ void __launch_bounds__(256) k_trans_init(const uint8_t *__restrict__ 
 int launch_trans_init(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, Shape s, float omega, float norm_eps,
                       int pre_clip, float *d_t0, hipStream_t st)
 {
-    const int blocks = grid_for(s.npx(), 4096);
+    const int blocks = grid_for((s.npx() + 3) / 4, 4096);
     UWIE_LAUNCH(k_trans_init, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_A, (int)s.npx(), omega,
                        norm_eps, pre_clip, d_t0);
     UWIE_LAUNCH_CHECK();
