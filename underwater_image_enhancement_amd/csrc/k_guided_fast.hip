@@ -2,17 +2,24 @@
 // summation order is not required (uwie_params.gf_exact == 0, the default).
 //
 // The exact-order path (k_guided.hip) must materialise the running-sum planes: 6 float64 planes, ~140 B/px of HBM
-// traffic.  Here a workgroup owns a 64-column strip of one image and streams down its rows once; everything between
-// the 5 B/px input (gray u8 + t0 f32) and the 8 B/px output (t, float64) lives in LDS and registers.  Both box
-// filters are evaluated vertical-first (the box is separable, the order of the two passes is free here):
-//   tick t, interval 1:  store the prefetched input row t into the raw ring (k+2 rows of {t0, gray})
-//                        V1[4 planes][column] += derived(row t-1) - derived(row t-k-1)     (registers, running)
-//                        V2[a,b][column]      += ab(row r1-2) - ab(row r1-k-2)             (registers, running)
-//           interval 2:  k-tap horizontal sums of V1 -> means of I, p, I*p, I*I for a/b row r1 = t - L
-//                        k-tap horizontal sums of V2 -> mean_a, mean_b for output row y2 = t - 2L - 1
-//           interval 3:  a = cov/(var+eps), b = mean_p - a*mean_I -> ab ring (k+2 rows);
-//                        q = mean_a*I + mean_b, clip -> HBM
-// (L = k - k/2; interval 3 shares a barrier interval with the next tick's interval 1: two barriers per row; input rows are prefetched into registers 8-16 rows ahead.)
+// traffic.  Here a workgroup (1024 threads) owns a 64-column strip of one image and streams down its rows once,
+// TH rows per step; everything between the 5 B/px input (gray u8 + t0 f32) and the 8 B/px output (t, float64) lives
+// in LDS and registers.  Both box filters are evaluated vertical-first (the box is separable):
+//   step m (input rows t = m*TH .. m*TH+TH-1):
+//     A1  finish the previous step: a = cov/(var+eps), b = mean_p - a*mean_I -> ab ring;  q = mean_a*I + mean_b,
+//         clip -> HBM                                                   (consumes the means of the previous step)
+//     A2  store the prefetched input rows into the raw ring {t0, gray}; issue the prefetch of the next TH rows
+//     --- barrier ---
+//     A3  vertical running sums, TH rows in sequence per column (registers):
+//           V1[I, p, I*p, I*I][column] += derived(entering row) - derived(leaving row)      -> vrow[TH]
+//           V2[a, b][column]           += ab(entering row) - ab(leaving row)                -> v2row[TH]
+//     --- barrier ---
+//     B   k-tap horizontal sums of all TH rows (3520 independent tasks for k = 15)          -> mrow[TH], m2row[TH]
+//     --- barrier ---
+// Three barriers per TH rows, and the wide phases (A1, B) have thousands of independent tasks, so the long LDS and
+// float64 latencies overlap instead of adding up row by row.  Lags: a/b row r1 = t - L, output row
+// y2 = t - 2L - 1 - TH (L = k - k/2; the extra TH keeps every a/b row a step's vertical update touches already
+// finished by A1).
 // Window = [i - k/2, i - k/2 + k - 1] with BORDER_REFLECT_101 in both directions, exactly OpenCV's box; only the ORDER
 // of the float64 additions differs from cv2.boxFilter's running sums (both add the same <= k*k terms), which moves t
 // by ~1e-15.  Stated tolerance: |t - t_oracle| <= 1e-11 (tests/test_gpu_stages.py); the pipeline's u8 output stays
@@ -25,33 +32,37 @@ namespace uwie {
 namespace {
 
 constexpr int kStripW = 64;
+constexpr int kFastThreads = 1024;
 
 struct FastGeom {
-    int H, W, k, a, L, RCraw, RCab, NC1, NCINMAX;
-    uint32_t Mraw, Mab;  // ceil(2^32 / RC): row % RC without an integer division in the row loop
+    int H, W, k, a, L, TH, RCraw, RCab, RCg, NC1, NCM;
+    uint32_t Mraw, Mab, Mg;  // ceil(2^32 / RC): row % RC without an integer division in the row loop
     size_t lds_bytes;
 };
 
-FastGeom make_fast_geom(Shape s, int k)
+FastGeom make_fast_geom(Shape s, int k, int TH)
 {
     FastGeom g;
-    g.H = s.H; g.W = s.W; g.k = k;
+    g.H = s.H; g.W = s.W; g.k = k; g.TH = TH;
     g.a = k / 2;
     g.L = k - g.a;
-    g.RCab = k + 3;
-    g.RCraw = (k + 2 > 2 * g.L + 3) ? k + 2 : 2 * g.L + 3;
+    g.RCraw = k + TH + 2;
+    g.RCab = 2 * TH + k + 3;
+    g.RCg = 2 * g.L + 3 * TH + 3;  // A1 reads row y2 while A2 (same barrier interval) stores rows up to tb+TH-1
     g.NC1 = kStripW + k - 1;
-    g.NCINMAX = kStripW + 4 * (k - 1);
-    const size_t doubles = (size_t)g.RCraw * g.NCINMAX          // raw ring: float2 {t0, gray}
-                           + 4 * (size_t)g.NCINMAX              // vrow
-                           + 4 * (size_t)g.NC1                  // mrow
-                           + (size_t)g.RCab * 2 * g.NC1         // ab ring
-                           + 2 * (size_t)g.NC1                  // v2row
-                           + 2 * (size_t)kStripW                // m2row
-                           + 256;                               // ilut
+    g.NCM = kStripW + 4 * (k - 1);
+    const size_t doubles = (size_t)g.RCraw * g.NCM            // raw ring: float2 {t0, gray}
+                           + (size_t)TH * 4 * g.NCM           // vrow
+                           + (size_t)TH * 4 * g.NC1           // mrow
+                           + (size_t)g.RCab * 2 * g.NC1       // ab ring
+                           + (size_t)TH * 2 * g.NC1           // v2row
+                           + (size_t)TH * 2 * kStripW         // m2row
+                           + 256                              // ilut
+                           + ((size_t)g.RCg * kStripW + 7) / 8;  // gray ring (bytes)
     g.lds_bytes = doubles * sizeof(double);
     g.Mraw = (uint32_t)(((1ull << 32) + g.RCraw - 1) / g.RCraw);
     g.Mab = (uint32_t)(((1ull << 32) + g.RCab - 1) / g.RCab);
+    g.Mg = (uint32_t)(((1ull << 32) + g.RCg - 1) / g.RCg);
     return g;
 }
 
@@ -75,40 +86,62 @@ __device__ __forceinline__ double ksum(const double *q, int k)
     return (s0 + s1) + s2;
 }
 
-__global__ void __launch_bounds__(256) k_guided_fast(const uint8_t *__restrict__ gray, const float *__restrict__ t0,
-                                                     double *__restrict__ tout, FastGeom g, double eps)
+template <int TH>
+__global__ void __launch_bounds__(kFastThreads) k_guided_fast(const uint8_t *__restrict__ gray,
+                                                              const float *__restrict__ t0, double *__restrict__ tout,
+                                                              FastGeom g, double eps)
 {
+    constexpr int NT = kFastThreads, TW = kStripW;
+    constexpr int MAXP = 4;  // horizontal stage-1 tasks per thread: TH * 4 * NC1 <= MAXP * NT
     extern __shared__ double sm[];
-    const int tid = threadIdx.x, b = blockIdx.y, x0 = blockIdx.x * kStripW;
-    const int H = g.H, W = g.W, k = g.k, a = g.a, L = g.L, NC1 = g.NC1, NCM = g.NCINMAX, TW = kStripW;
-    float2 *raw = reinterpret_cast<float2 *>(sm);      // [RCraw][NCM]  {t0, gray}
-    double *vrow = sm + (size_t)g.RCraw * NCM;         // [4][NCM]  vertical sums of I, p, I*p, I*I
-    double *mrow = vrow + 4 * (size_t)NCM;             // [4][NC1]  their window means
-    double *abr = mrow + 4 * (size_t)NC1;              // [RCab][2][NC1]
-    double *v2row = abr + (size_t)g.RCab * 2 * NC1;    // [2][NC1]  vertical sums of a, b
-    double *m2row = v2row + 2 * (size_t)NC1;           // [2][TW]
-    double *ilut = m2row + 2 * (size_t)TW;             // [256]
-    ilut[tid] = (double)tid / 255.0;                   // six_stadigy.py:177
+    const int tid = threadIdx.x, b = blockIdx.y, x0 = blockIdx.x * TW;
+    const int H = g.H, W = g.W, k = g.k, a = g.a, L = g.L, NC1 = g.NC1, NCM = g.NCM;
+    float2 *raw = reinterpret_cast<float2 *>(sm);       // [RCraw][NCM]  {t0, gray}
+    double *vrow = sm + (size_t)g.RCraw * NCM;          // [TH][4][NCM]  vertical sums of I, p, I*p, I*I
+    double *mrow = vrow + (size_t)TH * 4 * NCM;         // [TH][4][NC1]  their window means
+    double *abr = mrow + (size_t)TH * 4 * NC1;          // [RCab][2][NC1]
+    double *v2row = abr + (size_t)g.RCab * 2 * NC1;     // [TH][2][NC1]  vertical sums of a, b
+    double *m2row = v2row + (size_t)TH * 2 * NC1;       // [TH][2][TW]
+    double *ilut = m2row + (size_t)TH * 2 * TW;         // [256]
+    uint8_t *gring = reinterpret_cast<uint8_t *>(ilut + 256);  // [RCg][TW] gray of the output columns
+    if (tid < 256) ilut[tid] = (double)tid / 255.0;     // six_stadigy.py:177
 
     const int cmin = max(0, x0 - 2 * (k - 1)), cmax = min(W, x0 + TW + 2 * (k - 1)), ncin = cmax - cmin;
     const double scale = 1.0 / ((double)k * (double)k);
     const size_t img = (size_t)b * H * W;
-    const int ntask1 = 4 * NC1;
+    const int nrow1 = 4 * NC1;  // horizontal stage-1 tasks per row: (plane, a/b column)
 
-    // horizontal stage-1 task geometry: task -> (plane, a/b column); its window starts at actual column xr - a
-    int t1_off[2], t1_base[2];
-    bool t1_fast[2], t1_need[2];
+    // ---- static task descriptors
+    // ingest: thread -> (row-in-step, input column)
+    const int in_i = tid / ncin, in_c = tid - in_i * ncin;
+    const bool in_ok = in_i < TH;
+    // horizontal stage 1: task = i * nrow1 + pl * NC1 + col
+    int h1_i[MAXP], h1_src[MAXP], h1_dst[MAXP], h1_base[MAXP];
+    bool h1_fast[MAXP], h1_need[MAXP], h1_ok[MAXP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int task = tid + 256 * i;
-        const int pl = task < ntask1 ? task / NC1 : 0, col = task < ntask1 ? task % NC1 : 0;
-        const int xe = x0 - a + col;
-        const int xr = reflect101(xe, W);
-        t1_need[i] = task < ntask1 && xe <= W - 1 + (k - 1 - a);  // columns past that feed no real output pixel
-        t1_base[i] = xr - a;
-        t1_fast[i] = xr - a >= 0 && xr - a + k - 1 < W;
-        t1_off[i] = pl;  // plane; column recomputed from task
+    for (int j = 0; j < MAXP; ++j) {
+        const int task = tid + NT * j;
+        h1_ok[j] = task < TH * nrow1;
+        const int i = h1_ok[j] ? task / nrow1 : 0, rem = h1_ok[j] ? task - i * nrow1 : 0;
+        const int pl = rem / NC1, col = rem - pl * NC1;
+        const int xe = x0 - a + col, xr = reflect101(xe, W);
+        h1_i[j] = i;
+        h1_src[j] = (i * 4 + pl) * NCM;
+        h1_dst[j] = (i * 4 + pl) * NC1 + col;
+        h1_base[j] = xr - a;
+        h1_need[j] = h1_ok[j] && xe <= W - 1 + (k - 1 - a);  // columns past that feed no real output pixel
+        h1_fast[j] = xr - a >= 0 && xr - a + k - 1 < W;
     }
+    // horizontal stage 2: task = i * 2*TW + pl * TW + x  (TH * 128 <= NT)
+    const bool h2_ok = tid < TH * 2 * TW;
+    const int h2_i = tid / (2 * TW), h2_pl = (tid / TW) & 1, h2_x = tid & (TW - 1);
+    // finish (A1): a/b task = i * NC1 + col (threads 0 .. TH*NC1-1); output task = i * TW + x (threads from NT-TH*TW)
+    const int ab_i = tid / NC1, ab_c = tid - ab_i * NC1;
+    const bool ab_ok = ab_i < TH;
+    const int out_t = tid - (NT - TH * TW);
+    const bool out_ok = out_t >= 0;
+    const int out_i = out_ok ? out_t / TW : 0, out_x = out_ok ? out_t & (TW - 1) : 0;
+
     auto derive = [&](const float2 r, double *d) {
         const double I = ilut[(int)r.y], p = (double)r.x;
         d[0] = I;
@@ -118,144 +151,156 @@ __global__ void __launch_bounds__(256) k_guided_fast(const uint8_t *__restrict__
     };
 
     double V1[4] = {0.0, 0.0, 0.0, 0.0}, V2[2] = {0.0, 0.0};
-    // Input rows are prefetched a whole group of kGroup rows ahead into registers: a strip walks down the frame one
-    // row per tick, every row is a fresh set of cache lines (and mostly a fresh page), and with three barriers per
-    // tick nothing else hides that latency.
-    constexpr int kGroup = 8;
-    float cur_t[kGroup], nxt_t[kGroup];
-    uint32_t cur_g[kGroup], nxt_g[kGroup];
-#pragma unroll
-    for (int i = 0; i < kGroup; ++i) {
-        cur_t[i] = nxt_t[i] = 0.f;
-        cur_g[i] = nxt_g[i] = 0;
-        if (i < H && tid < ncin) {
-            const size_t idx = img + (size_t)i * W + cmin + tid;
-            cur_t[i] = t0[idx];
-            cur_g[i] = gray[idx];
-        }
+    float pre_t = 0.f;
+    uint32_t pre_g = 0;
+    if (in_ok && in_i < H) {
+        const size_t idx = img + (size_t)in_i * W + cmin + in_c;
+        pre_t = t0[idx];
+        pre_g = gray[idx];
     }
     __syncthreads();
 
-    // a/b row and output row of tick tt (consumes the means written in tick tt's interval 2); executed at the start
-    // of tick tt+1, in the same barrier interval as that tick's vertical updates (they touch disjoint LDS rows)
-    auto finish_tick = [&](int tt) {
-        const int r1 = tt - L, y2 = tt - 2 * L - 1;
-        const bool do1 = r1 >= 0 && r1 < H, do2 = y2 >= 0 && y2 < H;
-        if (do1 && tid < NC1) {
-            const double mI = mrow[tid], mp = mrow[NC1 + tid], mIp = mrow[2 * NC1 + tid], mII = mrow[3 * NC1 + tid];
-            const double cov = mIp - mI * mp, var = mII - mI * mI;
-            const double av = cov / (var + eps);
-            double *dst = abr + (size_t)fast_mod(r1, g.RCab, g.Mab) * 2 * NC1;
-            dst[tid] = av;
-            dst[NC1 + tid] = mp - av * mI;
-        }
-        if (do2 && tid >= 128 && tid < 128 + TW) {
-            const int x = tid - 128;
-            if (x0 + x < W) {
-                const float2 r = raw[(size_t)fast_mod(y2, g.RCraw, g.Mraw) * NCM + (x0 + x - cmin)];
-                const double q = m2row[x] * ilut[(int)r.y] + m2row[TW + x];
-                tout[img + (size_t)y2 * W + x0 + x] = fmin(fmax(q, 0.1), 1.0);
-            }
-        }
-    };
-
-    // a/b row r1 lags the input by L rows; the output row lags r1 by L + 1 (one more than the window needs, so that
-    // every a/b row an output window touches -- including the reflected row k/2 of an even k -- is already stored)
-    for (int tg = 0; tg <= H + 2 * L; tg += kGroup) {
-#pragma unroll
-        for (int i = 0; i < kGroup; ++i) {
-            const int row = tg + kGroup + i;
-            if (row < H && tid < ncin) {
-                const size_t idx = img + (size_t)row * W + cmin + tid;
-                nxt_t[i] = t0[idx];
-                nxt_g[i] = gray[idx];
-            }
-        }
-#pragma unroll
-      for (int gi = 0; gi < kGroup; ++gi) {
-        const int t = tg + gi;
-        if (t > H + 2 * L) break;
-        const int r1 = t - L, y2 = t - 2 * L - 1;
-        const bool do1 = r1 >= 0 && r1 < H, do2 = y2 >= 0 && y2 < H;
-        // ================= interval 1: finish the previous tick; ring store, vertical running sums =================
-        if (t > 0) finish_tick(t - 1);
-        if (t < H && tid < ncin)
-            raw[(size_t)fast_mod(t, g.RCraw, g.Mraw) * NCM + tid] = make_float2(cur_t[gi], (float)cur_g[gi]);
-        if (do1 && tid < ncin) {
-            // rows entering/leaving the window of a/b row r1 are <= t-1: stored in earlier ticks
-            if (r1 == 0) {
-                double acc[4] = {0.0, 0.0, 0.0, 0.0}, d[4];
-                for (int j = 0; j < k; ++j) {
-                    const int row = reflect101(j - a, H);
-                    // row t (== L for even k) is being stored by this very thread in this tick: use the registers
-                    derive(raw[(size_t)fast_mod(row, g.RCraw, g.Mraw) * NCM + tid], d);
-                    acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2]; acc[3] += d[3];
+    const int t_end = H + 2 * L + TH;  // last tick that still produces an output row
+    for (int tb = 0; tb <= t_end + TH; tb += TH) {
+        // ================= A1: finish the previous step =================
+        if (tb > 0) {
+            const int tp = tb - TH;
+            if (ab_ok) {
+                const int r1 = tp + ab_i - L;
+                if (r1 >= 0 && r1 < H) {
+                    const double *m = mrow + (size_t)ab_i * 4 * NC1 + ab_c;
+                    const double mI = m[0], mp = m[NC1], mIp = m[2 * NC1], mII = m[3 * NC1];
+                    const double cov = mIp - mI * mp, var = mII - mI * mI;
+                    const double av = cov / (var + eps);
+                    double *dst = abr + (size_t)fast_mod(r1, g.RCab, g.Mab) * 2 * NC1;
+                    dst[ab_c] = av;
+                    dst[NC1 + ab_c] = mp - av * mI;
                 }
-                V1[0] = acc[0]; V1[1] = acc[1]; V1[2] = acc[2]; V1[3] = acc[3];
-            } else {
-                double e[4], l[4];
-                derive(raw[(size_t)fast_mod(reflect101(r1 - a + k - 1, H), g.RCraw, g.Mraw) * NCM + tid], e);
-                derive(raw[(size_t)fast_mod(reflect101(r1 - 1 - a, H), g.RCraw, g.Mraw) * NCM + tid], l);
-                V1[0] += e[0] - l[0]; V1[1] += e[1] - l[1]; V1[2] += e[2] - l[2]; V1[3] += e[3] - l[3];
             }
-            vrow[tid] = V1[0];
-            vrow[NCM + tid] = V1[1];
-            vrow[2 * NCM + tid] = V1[2];
-            vrow[3 * NCM + tid] = V1[3];
-        }
-        if (do2 && tid < NC1) {
-            if (y2 == 0) {
-                double s0 = 0.0, s1 = 0.0;
-                for (int j = 0; j < k; ++j) {
-                    const double *q = abr + (size_t)fast_mod(reflect101(j - a, H), g.RCab, g.Mab) * 2 * NC1;
-                    s0 += q[tid];
-                    s1 += q[NC1 + tid];
+            if (out_ok) {
+                const int y2 = tp + out_i - 2 * L - 1 - TH;
+                if (y2 >= 0 && y2 < H && x0 + out_x < W) {
+                    const double *m = m2row + (size_t)out_i * 2 * TW;
+                    const double I = ilut[gring[fast_mod(y2, g.RCg, g.Mg) * TW + out_x]];
+                    const double q = m[out_x] * I + m[TW + out_x];
+                    tout[img + (size_t)y2 * W + x0 + out_x] = fmin(fmax(q, 0.1), 1.0);
                 }
-                V2[0] = s0;
-                V2[1] = s1;
-            } else {
-                const double *e = abr + (size_t)fast_mod(reflect101(y2 - a + k - 1, H), g.RCab, g.Mab) * 2 * NC1;
-                const double *l = abr + (size_t)fast_mod(reflect101(y2 - 1 - a, H), g.RCab, g.Mab) * 2 * NC1;
-                V2[0] += e[tid] - l[tid];
-                V2[1] += e[NC1 + tid] - l[NC1 + tid];
             }
-            v2row[tid] = V2[0];
-            v2row[NC1 + tid] = V2[1];
+        }
+        // ================= A2: ring store + prefetch =================
+        if (in_ok) {
+            const int t = tb + in_i;
+            if (t < H) {
+                raw[(size_t)fast_mod(t, g.RCraw, g.Mraw) * NCM + in_c] = make_float2(pre_t, (float)pre_g);
+                const int xo = cmin + in_c - x0;
+                if (xo >= 0 && xo < TW) gring[fast_mod(t, g.RCg, g.Mg) * TW + xo] = (uint8_t)pre_g;
+            }
+            const int tn = t + TH;
+            if (tn < H) {
+                const size_t idx = img + (size_t)tn * W + cmin + in_c;
+                pre_t = t0[idx];
+                pre_g = gray[idx];
+            }
         }
         __syncthreads();
-        // ================= interval 2: horizontal k-tap sums =================
-        // 4*NC1 stage-1 tasks (thread tid takes task tid; the surplus goes to threads 0..127) and 2*TW stage-2 tasks
-        // (threads 128..255), so every wave runs at most two k-tap sums
-        if (do1) {
+        // ================= A3: vertical running sums, TH rows in sequence =================
+        if (tid < ncin) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int task = tid + 256 * i;
-                if (task < ntask1 && (i == 0 || tid < 128)) {
-                    const double *src = vrow + (size_t)t1_off[i] * NCM;
-                    double s = 0.0;
-                    if (!t1_need[i]) {
-                    } else if (t1_fast[i]) {
-                        s = ksum(src + (t1_base[i] - cmin), k);
-                    } else {
-                        for (int j = 0; j < k; ++j) s += src[reflect101(t1_base[i] + j, W) - cmin];
+            for (int i = 0; i < TH; ++i) {
+                const int r1 = tb + i - L;
+                if (r1 < 0 || r1 >= H) continue;
+                if (r1 == 0) {
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0}, d[4];
+                    for (int j = 0; j < k; ++j) {
+                        derive(raw[(size_t)fast_mod(reflect101(j - a, H), g.RCraw, g.Mraw) * NCM + tid], d);
+                        acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2]; acc[3] += d[3];
                     }
-                    mrow[task] = s * scale;  // task == plane * NC1 + column
+                    V1[0] = acc[0]; V1[1] = acc[1]; V1[2] = acc[2]; V1[3] = acc[3];
+                } else {
+                    double e[4], l[4];
+                    derive(raw[(size_t)fast_mod(reflect101(r1 - a + k - 1, H), g.RCraw, g.Mraw) * NCM + tid], e);
+                    derive(raw[(size_t)fast_mod(reflect101(r1 - 1 - a, H), g.RCraw, g.Mraw) * NCM + tid], l);
+                    V1[0] += e[0] - l[0]; V1[1] += e[1] - l[1]; V1[2] += e[2] - l[2]; V1[3] += e[3] - l[3];
                 }
+                double *v = vrow + (size_t)i * 4 * NCM + tid;
+                v[0] = V1[0];
+                v[NCM] = V1[1];
+                v[2 * NCM] = V1[2];
+                v[3 * NCM] = V1[3];
+            }
+        } else if (tid >= 512 && tid < 512 + NC1) {
+            const int c = tid - 512;
+#pragma unroll
+            for (int i = 0; i < TH; ++i) {
+                const int y2 = tb + i - 2 * L - 1 - TH;
+                if (y2 < 0 || y2 >= H) continue;
+                if (y2 == 0) {
+                    double s0 = 0.0, s1 = 0.0;
+                    for (int j = 0; j < k; ++j) {
+                        const double *q = abr + (size_t)fast_mod(reflect101(j - a, H), g.RCab, g.Mab) * 2 * NC1;
+                        s0 += q[c];
+                        s1 += q[NC1 + c];
+                    }
+                    V2[0] = s0;
+                    V2[1] = s1;
+                } else {
+                    const double *e = abr + (size_t)fast_mod(reflect101(y2 - a + k - 1, H), g.RCab, g.Mab) * 2 * NC1;
+                    const double *l = abr + (size_t)fast_mod(reflect101(y2 - 1 - a, H), g.RCab, g.Mab) * 2 * NC1;
+                    V2[0] += e[c] - l[c];
+                    V2[1] += e[NC1 + c] - l[NC1 + c];
+                }
+                double *v = v2row + (size_t)i * 2 * NC1 + c;
+                v[0] = V2[0];
+                v[NC1] = V2[1];
             }
         }
-        if (do2 && tid >= 128) {
-            const int u = tid - 128, pl = u / TW, x = u % TW;
-            m2row[u] = ksum(v2row + pl * NC1 + x, k) * scale;
+        __syncthreads();
+        // ================= B: horizontal k-tap sums of all TH rows =================
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            if (!h1_ok[j]) continue;
+            const int r1 = tb + h1_i[j] - L;
+            if (r1 < 0 || r1 >= H) continue;
+            const double *src = vrow + h1_src[j];
+            double s = 0.0;
+            if (!h1_need[j]) {
+            } else if (h1_fast[j]) {
+                s = ksum(src + (h1_base[j] - cmin), k);
+            } else {
+                for (int q = 0; q < k; ++q) s += src[reflect101(h1_base[j] + q, W) - cmin];
+            }
+            mrow[h1_dst[j]] = s * scale;
+        }
+        if (h2_ok) {
+            const int y2 = tb + h2_i - 2 * L - 1 - TH;
+            if (y2 >= 0 && y2 < H)
+                m2row[(size_t)h2_i * 2 * TW + h2_pl * TW + h2_x] =
+                    ksum(v2row + (size_t)h2_i * 2 * NC1 + h2_pl * NC1 + h2_x, k) * scale;
         }
         __syncthreads();
-      }
-#pragma unroll
-        for (int i = 0; i < kGroup; ++i) {
-            cur_t[i] = nxt_t[i];
-            cur_g[i] = nxt_g[i];
-        }
     }
-    finish_tick(H + 2 * L);
+}
+
+template <int TH>
+int launch_th(const uint8_t *d_gray, const float *d_t0, Shape s, const FastGeom &g, double eps, double *d_t, hipStream_t st)
+{
+    static thread_local size_t attr_set = 0;
+    if (g.lds_bytes > 64 * 1024 && g.lds_bytes > attr_set) {
+        UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_guided_fast<TH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        attr_set = g.lds_bytes;
+    }
+    UWIE_LAUNCH(k_guided_fast<TH>, dim3(cdiv(s.W, kStripW), s.B), dim3(kFastThreads), g.lds_bytes, st, d_gray, d_t0, d_t, g,
+                eps);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+bool fits(const FastGeom &g, int TH)
+{
+    return g.lds_bytes <= 160 * 1024 && TH * g.NCM <= kFastThreads && TH * 4 * g.NC1 <= 4 * kFastThreads &&
+           TH * g.NC1 <= kFastThreads && TH * 2 * kStripW <= kFastThreads && 512 + g.NC1 <= kFastThreads && g.NCM <= 512 &&
+           g.H < (1 << 20);
 }
 
 }  // namespace
@@ -265,19 +310,15 @@ __global__ void __launch_bounds__(256) k_guided_fast(const uint8_t *__restrict__
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
                        hipStream_t st)
 {
-    const FastGeom g = make_fast_geom(s, k);
     *handled = 0;
-    if (g.lds_bytes > 150 * 1024 || 4 * g.NC1 > 384 || g.NCINMAX > 256 || s.H >= (1 << 20)) return UWIE_OK;
-    static thread_local size_t attr_set = 0;
-    if (g.lds_bytes > 64 * 1024 && g.lds_bytes > attr_set) {
-        UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_guided_fast),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-        attr_set = g.lds_bytes;
-    }
-    UWIE_LAUNCH(k_guided_fast, dim3(cdiv(s.W, kStripW), s.B), dim3(256), g.lds_bytes, st, d_gray, d_t0, d_t, g, eps);
-    UWIE_LAUNCH_CHECK();
-    *handled = 1;
-    return UWIE_OK;
+    const FastGeom g8 = make_fast_geom(s, k, 8), g4 = make_fast_geom(s, k, 4), g2 = make_fast_geom(s, k, 2);
+    int rc = UWIE_OK;
+    if (fits(g8, 8)) rc = launch_th<8>(d_gray, d_t0, s, g8, eps, d_t, st);
+    else if (fits(g4, 4)) rc = launch_th<4>(d_gray, d_t0, s, g4, eps, d_t, st);
+    else if (fits(g2, 2)) rc = launch_th<2>(d_gray, d_t0, s, g2, eps, d_t, st);
+    else return UWIE_OK;
+    if (rc == UWIE_OK) *handled = 1;
+    return rc;
 }
 
 }  // namespace uwie
