@@ -134,6 +134,61 @@ __device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, f
     out[0] = res[0]; out[1] = res[1]; out[2] = res[2];
 }
 
+// The same for a full 128-element leaf, eight pixels per step: when the eight pixels lie in one row of the region
+// their 24 bytes come in as six (unaligned) dword loads instead of 24 byte loads.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+template <bool VAR>
+__device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, float out[3])
+{
+    int ly = e0 / r.cols, lx = e0 % r.cols;
+    const uint8_t *p = el.img + ((size_t)(r.y0 + ly) * el.W + r.x0 + lx) * 3;
+    float acc[3][8];
+    for (int it = 0; it < 16; ++it) {
+        uint8_t px[24];
+        if (lx + 8 <= r.cols) {
+            const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(p);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const uint32_t v = w[q];
+                px[4 * q] = (uint8_t)v;
+                px[4 * q + 1] = (uint8_t)(v >> 8);
+                px[4 * q + 2] = (uint8_t)(v >> 16);
+                px[4 * q + 3] = (uint8_t)(v >> 24);
+            }
+            lx += 8;
+            p += 24;
+            if (lx == r.cols) {
+                lx = 0;
+                p += (size_t)(el.W - r.cols) * 3;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                px[3 * j] = p[0];
+                px[3 * j + 1] = p[1];
+                px[3 * j + 2] = p[2];
+                ++lx;
+                p += 3;
+                if (lx == r.cols) {
+                    lx = 0;
+                    p += (size_t)(el.W - r.cols) * 3;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = el.get(px + 3 * j, c);
+                acc[c][j] = it == 0 ? v : acc[c][j] + v;
+            }
+    }
+    out[0] = tree8(acc[0]);
+    out[1] = tree8(acc[1]);
+    out[2] = tree8(acc[2]);
+}
+
 // One wavefront per (chunk, region).  csum[(reg*maxChunks + chunk)*3 + c] = pairwise sum of that chunk.
 template <bool VAR>
 __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
@@ -170,7 +225,7 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     if (len == kNpChunk) {
         // balanced tree: 64 leaves of 128, lane = leaf, butterfly == recursive halving
         float s[3];
-        leaf_sum3<VAR>(el, r, c0 + lane * 128, 128, s);
+        leaf_sum3_full<VAR>(el, r, c0 + lane * 128, s);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             s[0] += __shfl_xor(s[0], o);

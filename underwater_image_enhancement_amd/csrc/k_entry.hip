@@ -107,17 +107,31 @@ __global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__
     __syncthreads();
     const uint8_t *chan = in + (size_t)b * npx * 3 + ch;
     float s = 0.0f;
+    // The only loop-carried value is s.  Everything that does not depend on it is kept off the critical path: the
+    // next chunk's histogram slice is prefetched, and the rounding-table row of the current binade stays in registers
+    // (it changes ~24 times per channel).
+    const uint4 *hp = reinterpret_cast<const uint4 *>(hist + (((size_t)b * nchunk) * 3 + ch) * 256 + lane * 4);
+    uint4 hnext = hp[0];
+    int ei_cached = -1;
+    uint32_t R0 = 0, R1 = 0, R2 = 0, R3 = 0;
+    bool t0 = false, t1 = false, t2 = false, t3 = false;
     for (int c = 0; c < nchunk; ++c) {
-        const uint32_t *h = hist + (((size_t)b * nchunk + c) * 3 + ch) * 256 + lane * 4;
-        const uint32_t h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+        const uint4 hv = hnext;
+        if (c + 1 < nchunk) hnext = hp[(size_t)(c + 1) * 192];  // 768 words per chunk = 192 uint4
+        const uint32_t h0 = hv.x, h1 = hv.y, h2 = hv.z, h3 = hv.w;
         bool done;
         if (s >= 0.25f) {
             const int e = (int)(__float_as_uint(s) >> 23) - 127;
             const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
-            const uint32_t *R = &tab->R[ei][lane * 4];
-            const uint8_t *Tt = &tab->tie[ei][lane * 4];
-            uint64_t D = (uint64_t)h0 * R[0] + (uint64_t)h1 * R[1] + (uint64_t)h2 * R[2] + (uint64_t)h3 * R[3];
-            uint32_t T = (h0 && Tt[0]) + (h1 && Tt[1]) + (h2 && Tt[2]) + (h3 && Tt[3]);
+            if (ei != ei_cached) {
+                const uint32_t *R = &tab->R[ei][lane * 4];
+                const uint8_t *Tt = &tab->tie[ei][lane * 4];
+                R0 = R[0]; R1 = R[1]; R2 = R[2]; R3 = R[3];
+                t0 = Tt[0] != 0; t1 = Tt[1] != 0; t2 = Tt[2] != 0; t3 = Tt[3] != 0;
+                ei_cached = ei;
+            }
+            uint64_t D = (uint64_t)h0 * R0 + (uint64_t)h1 * R1 + (uint64_t)h2 * R2 + (uint64_t)h3 * R3;
+            uint32_t T = (h0 && t0) + (h1 && t1) + (h2 && t2) + (h3 && t3);
             D = wave_sum_u64(D);
             T = wave_sum_u32(T);
             const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;

@@ -10,13 +10,14 @@
 //         clip -> HBM                                                   (consumes the means of the previous step)
 //     A2  store the prefetched input rows into the raw ring {t0, gray}; issue the prefetch of the next TH rows
 //     --- barrier ---
-//     A3  vertical running sums, TH rows in sequence per column (registers):
-//           V1[I, p, I*p, I*I][column] += derived(entering row) - derived(leaving row)      -> vrow[TH]
-//           V2[a, b][column]           += ab(entering row) - ab(leaving row)                -> v2row[TH]
+//     A3a per-row differences derived(entering row) - derived(leaving row) of I, p, I*p, I*I, and of a, b,
+//         for all TH rows at once (one task per row and column)
+//     --- barrier ---
+//     A3b vertical running sums: one thread per (plane, column) adds the TH differences in sequence -> vrow, v2row
 //     --- barrier ---
 //     B   k-tap horizontal sums of all TH rows (3520 independent tasks for k = 15)          -> mrow[TH], m2row[TH]
 //     --- barrier ---
-// Three barriers per TH rows, and the wide phases (A1, B) have thousands of independent tasks, so the long LDS and
+// Four barriers per TH rows, and the wide phases (A1, B) have thousands of independent tasks, so the long LDS and
 // float64 latencies overlap instead of adding up row by row.  Lags: a/b row r1 = t - L, output row
 // y2 = t - 2L - 1 - TH (L = k - k/2; the extra TH keeps every a/b row a step's vertical update touches already
 // finished by A1).
@@ -73,8 +74,26 @@ __device__ __forceinline__ int fast_mod(int row, int rc, uint32_t m)
     return r < 0 ? r + rc : r;
 }
 
+// k-tap sum.  For the window widths the reference uses (six_stadigy.py:234,245,255 and config.py: 10, 15, 20) the loop
+// is fully unrolled: all loads issue back to back and the adds form a short tree, one LDS round trip instead of k/3.
+template <int K>
+__device__ __forceinline__ double ksum_fixed(const double *q)
+{
+    double v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) v[j] = q[j];
+#pragma unroll
+    for (int w = 1; w < K; w *= 2)
+#pragma unroll
+        for (int j = 0; j + w < K; j += 2 * w) v[j] += v[j + w];
+    return v[0];
+}
+
 __device__ __forceinline__ double ksum(const double *q, int k)
 {
+    if (k == 15) return ksum_fixed<15>(q);
+    if (k == 20) return ksum_fixed<20>(q);
+    if (k == 10) return ksum_fixed<10>(q);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     int j = 0;
     for (; j + 2 < k; j += 3) {
@@ -150,7 +169,7 @@ __global__ void __launch_bounds__(kFastThreads) k_guided_fast(const uint8_t *__r
         d[3] = I * I;
     };
 
-    double V1[4] = {0.0, 0.0, 0.0, 0.0}, V2[2] = {0.0, 0.0};
+    double V1 = 0.0, V2 = 0.0;  // running vertical sums of this thread's (plane, column)
     float pre_t = 0.f;
     uint32_t pre_g = 0;
     if (in_ok && in_i < H) {
@@ -203,55 +222,67 @@ __global__ void __launch_bounds__(kFastThreads) k_guided_fast(const uint8_t *__r
             }
         }
         __syncthreads();
-        // ================= A3: vertical running sums, TH rows in sequence =================
-        if (tid < ncin) {
+        // ================= A3a: per-row differences (entering - leaving), all rows of the step in parallel =================
+        if (in_ok) {  // stage 1: task (row-in-step in_i, input column in_c)
+            const int r1 = tb + in_i - L;
+            if (r1 > 0 && r1 < H) {
+                double e[4], l[4];
+                derive(raw[(size_t)fast_mod(reflect101(r1 - a + k - 1, H), g.RCraw, g.Mraw) * NCM + in_c], e);
+                derive(raw[(size_t)fast_mod(reflect101(r1 - 1 - a, H), g.RCraw, g.Mraw) * NCM + in_c], l);
+                double *v = vrow + (size_t)in_i * 4 * NCM + in_c;
+                v[0] = e[0] - l[0];
+                v[NCM] = e[1] - l[1];
+                v[2 * NCM] = e[2] - l[2];
+                v[3 * NCM] = e[3] - l[3];
+            }
+        }
+        if (ab_ok) {  // stage 2: task (row-in-step ab_i, a/b column ab_c)
+            const int y2 = tb + ab_i - 2 * L - 1 - TH;
+            if (y2 > 0 && y2 < H) {
+                const double *e = abr + (size_t)fast_mod(reflect101(y2 - a + k - 1, H), g.RCab, g.Mab) * 2 * NC1;
+                const double *l = abr + (size_t)fast_mod(reflect101(y2 - 1 - a, H), g.RCab, g.Mab) * 2 * NC1;
+                double *v = v2row + (size_t)ab_i * 2 * NC1 + ab_c;
+                v[0] = e[ab_c] - l[ab_c];
+                v[NC1] = e[NC1 + ab_c] - l[NC1 + ab_c];
+            }
+        }
+        __syncthreads();
+        // ================= A3b: running sums down the TH rows, one thread per (plane, column) =================
+        if (tid < 4 * ncin) {
+            const int pl = tid / ncin, c = tid - pl * ncin;
 #pragma unroll
             for (int i = 0; i < TH; ++i) {
                 const int r1 = tb + i - L;
                 if (r1 < 0 || r1 >= H) continue;
+                double *v = vrow + (size_t)(i * 4 + pl) * NCM + c;
                 if (r1 == 0) {
-                    double acc[4] = {0.0, 0.0, 0.0, 0.0}, d[4];
+                    double acc = 0.0, d[4];
                     for (int j = 0; j < k; ++j) {
-                        derive(raw[(size_t)fast_mod(reflect101(j - a, H), g.RCraw, g.Mraw) * NCM + tid], d);
-                        acc[0] += d[0]; acc[1] += d[1]; acc[2] += d[2]; acc[3] += d[3];
+                        derive(raw[(size_t)fast_mod(reflect101(j - a, H), g.RCraw, g.Mraw) * NCM + c], d);
+                        acc += pl == 0 ? d[0] : pl == 1 ? d[1] : pl == 2 ? d[2] : d[3];
                     }
-                    V1[0] = acc[0]; V1[1] = acc[1]; V1[2] = acc[2]; V1[3] = acc[3];
+                    V1 = acc;
                 } else {
-                    double e[4], l[4];
-                    derive(raw[(size_t)fast_mod(reflect101(r1 - a + k - 1, H), g.RCraw, g.Mraw) * NCM + tid], e);
-                    derive(raw[(size_t)fast_mod(reflect101(r1 - 1 - a, H), g.RCraw, g.Mraw) * NCM + tid], l);
-                    V1[0] += e[0] - l[0]; V1[1] += e[1] - l[1]; V1[2] += e[2] - l[2]; V1[3] += e[3] - l[3];
+                    V1 += *v;
                 }
-                double *v = vrow + (size_t)i * 4 * NCM + tid;
-                v[0] = V1[0];
-                v[NCM] = V1[1];
-                v[2 * NCM] = V1[2];
-                v[3 * NCM] = V1[3];
+                *v = V1;
             }
-        } else if (tid >= 512 && tid < 512 + NC1) {
-            const int c = tid - 512;
+        } else if (tid >= 512 && tid < 512 + 2 * NC1) {
+            const int u = tid - 512, pl = u / NC1, c = u - pl * NC1;
 #pragma unroll
             for (int i = 0; i < TH; ++i) {
                 const int y2 = tb + i - 2 * L - 1 - TH;
                 if (y2 < 0 || y2 >= H) continue;
+                double *v = v2row + (size_t)(i * 2 + pl) * NC1 + c;
                 if (y2 == 0) {
-                    double s0 = 0.0, s1 = 0.0;
-                    for (int j = 0; j < k; ++j) {
-                        const double *q = abr + (size_t)fast_mod(reflect101(j - a, H), g.RCab, g.Mab) * 2 * NC1;
-                        s0 += q[c];
-                        s1 += q[NC1 + c];
-                    }
-                    V2[0] = s0;
-                    V2[1] = s1;
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j)
+                        acc += abr[(size_t)fast_mod(reflect101(j - a, H), g.RCab, g.Mab) * 2 * NC1 + pl * NC1 + c];
+                    V2 = acc;
                 } else {
-                    const double *e = abr + (size_t)fast_mod(reflect101(y2 - a + k - 1, H), g.RCab, g.Mab) * 2 * NC1;
-                    const double *l = abr + (size_t)fast_mod(reflect101(y2 - 1 - a, H), g.RCab, g.Mab) * 2 * NC1;
-                    V2[0] += e[c] - l[c];
-                    V2[1] += e[NC1 + c] - l[NC1 + c];
+                    V2 += *v;
                 }
-                double *v = v2row + (size_t)i * 2 * NC1 + c;
-                v[0] = V2[0];
-                v[NC1] = V2[1];
+                *v = V2;
             }
         }
         __syncthreads();
@@ -299,7 +330,8 @@ int launch_th(const uint8_t *d_gray, const float *d_t0, Shape s, const FastGeom 
 bool fits(const FastGeom &g, int TH)
 {
     return g.lds_bytes <= 160 * 1024 && TH * g.NCM <= kFastThreads && TH * 4 * g.NC1 <= 4 * kFastThreads &&
-           TH * g.NC1 <= kFastThreads && TH * 2 * kStripW <= kFastThreads && 512 + g.NC1 <= kFastThreads && g.NCM <= 512 &&
+           TH * g.NC1 <= kFastThreads && TH * 2 * kStripW <= kFastThreads && 512 + 2 * g.NC1 <= kFastThreads &&
+           4 * g.NCM <= 512 &&
            g.H < (1 << 20);
 }
 
