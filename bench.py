@@ -34,7 +34,7 @@ KERNEL_BYTES_PER_PX = {
     "k_chunk_hist": 3, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
     "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_gradnms": (1 + 1) * Q,
     "k_canny_union": 1 * Q, "k_canny_flat": 1 * Q, "k_canny_mark": 1 * Q, "k_canny_emit": 1 * Q,
-    "k_trans_init": 3 + 4, "k_guided_fast": 1 + 4 + 8,
+    "k_trans_init": 3 + 4, "k_guided_fast<TH>": 1 + 4 + 8,
     "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
     "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
     "k_sel_hist<V>": 3 * 4, "k_restore_planar_hist": 3 + 8 + 12, "k_stretch_apply": 12 + 12, "k_quant_rgb2lab": 12 + 3, "k_clahe_lut": 1,
@@ -71,17 +71,30 @@ def cpu_baseline(H, W, seed, budget_s=25.0):
 
     from oracle import uwie_oracle as orc
 
-    frames = synth_underwater(2, H, W, torch.device("cpu"), seed).numpy()
+    frames = synth_underwater(8, H, W, torch.device("cpu"), seed).numpy()
     orc.enhance_u8(np.ascontiguousarray(frames[0, : H // 8, : W // 8]), 2)  # warm-up (library load, tables)
     done, t0 = 0, time.perf_counter()
     while done < len(frames):
         orc.enhance_u8(frames[done], 2)
         done += 1
-        if time.perf_counter() - t0 > budget_s * 0.5:
+        if time.perf_counter() - t0 > budget_s * 0.6:
             break
     dt = time.perf_counter() - t0
     return {"value": round(done * H * W / 1e6 / dt, 3), "unit": "megapixels/sec", "cores": 1, "kind": "port",
             "sample": f"{done} frame(s) of {W}x{H} through oracle.enhance_u8 (NumPy + C restatement, 1 thread), {dt:.1f} s"}
+
+
+def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this same workload (profiles/r01_traffic.json:
+    FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes), or None when the workload differs / was not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not (os.path.exists(path) and (H, W, strategy) == (2160, 3840, 2)):
+        return None
+    table = json.load(open(path))["kernels"]
+    key = kernel.replace("<TH>", "<8>").replace("<V>", "<float>")
+    if key not in table:
+        return None
+    return table[key]["hbm_bytes_per_px_per_step"] * B * H * W / max(launches_per_step, 1)
 
 
 def main():
@@ -165,7 +178,8 @@ def main():
                                    "(canonical enhance, BASELINE.json configs[2])",
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": name,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(name, H, W, B, args.strategy, launches_per_step), "kernel": name,
                          "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "kernel_share_of_step": round(ms / args.steps / (elapsed / args.steps * 1e3), 4),

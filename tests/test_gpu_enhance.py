@@ -145,3 +145,35 @@ def test_exact_order_guided_filter_mode(uw, orc, strategy):
         want = orc.enhance_u8(u8, strategy)
         assert np.array_equal(uw.enhance(u8, strategy=strategy, gf_exact=1), want)
         assert check_u8(uw.enhance(u8, strategy=strategy, gf_exact=0), want, name) == 0
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes
+def _underwater(rng, H, W, gains):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    field = 0.55 + 0.25 * (np.sin(xx / (W / 9.0)) * np.cos(yy / (H / 7.0)) + 0.5 * np.sin((xx + 2 * yy) / (W / 5.0))) / 1.5
+    f = field[:, :, None] * np.array(gains, np.float32)[None, None, :] + rng.normal(0, 0.02, (H, W, 3)).astype(np.float32)
+    return np.clip(np.floor(255 * f), 0, 255).astype(np.uint8)
+
+
+def test_config1_1080p_single_frame_matches_oracle(uw, orc):
+    """BASELINE.json configs[1]: 1920x1080 RGB, batch 1, full WB + DCP + guided filter + CLAHE."""
+    u8 = _underwater(np.random.default_rng(1001), 1080, 1920, (0.45, 0.85, 0.80))
+    got = uw.enhance(u8)
+    want = orc.enhance_u8(u8, 2)
+    n = check_u8(got, want, "1080p")
+    assert n <= 8, f"{n} bytes differ by 1 LSB"  # default (fused) guided filter: <= 1 LSB, practically identical
+    assert np.array_equal(uw.enhance(u8, gf_exact=1), want)  # exact-order mode: bit for bit
+
+
+def test_config2_4k_frame_matches_oracle_and_batch_is_invariant(uw, orc):
+    """BASELINE.json configs[2] frame size (3840x2160): one frame against the oracle, then the size-independent
+    properties on a batch: batch == singles, frame order does not matter, a 'normal' cast is the identity."""
+    rng = np.random.default_rng(1002)
+    frames = np.stack([_underwater(rng, 2160, 3840, (0.45, 0.85, 0.80)), _underwater(rng, 2160, 3840, (0.45, 0.75, 0.90)),
+                       rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)])
+    out = uw.enhance(frames)
+    assert check_u8(out[0], orc.enhance_u8(frames[0], 2), "4K frame") <= 32
+    for b in range(3):
+        assert np.array_equal(out[b], uw.enhance(frames[b]))
+    assert np.array_equal(uw.enhance(frames[::-1].copy())[::-1], out)
+    assert np.array_equal(uw.enhance(frames[2], cast_correct=False), out[2])  # neutral noise is classified "normal"
