@@ -87,3 +87,17 @@ def test_no_cpu_fallback_without_a_device():
 
     with pytest.raises(uw.UwieError):
         uw.enhance(np.zeros((8, 8, 3), np.uint8))
+
+
+def test_u8_over_255_identity():
+    """k_guided_wave.hip computes g/255.0 as fma(fma(-q0, 255, g), 1/255, q0) with q0 = g * (1/255): three operations
+    instead of a float64 division.  Checked here for every byte value with exact rational arithmetic (float(Fraction)
+    rounds correctly, so each line below is one IEEE operation)."""
+    from fractions import Fraction as F
+
+    rcp = 1.0 / 255.0
+    for g in range(256):
+        q0 = float(g) * rcp
+        r = float(F(g) - F(q0) * 255)
+        q1 = float(F(r) * F(rcp) + F(q0))
+        assert q1 == g / 255.0, g

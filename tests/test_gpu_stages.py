@@ -200,6 +200,26 @@ def test_transmission_init_and_guided_filter(dev, orc, frames):
             assert tf.dtype == np.float64 and np.abs(tf - want_t).max() <= 1e-11, (name, ks, np.abs(tf - want_t).max())
 
 
+@pytest.mark.parametrize("k", [15, 20, 10, 7])
+@pytest.mark.parametrize("shape", [(83, 101), (130, 227), (97, 300), (64, 39), (211, 128)])
+def test_fused_guided_filter_ragged_shapes(dev, orc, k, shape):
+    """Default (gf_exact=0) guided filter on sizes that exercise every dispatch: one strip / several strips with a ragged
+    last one, several bands, both image borders inside one strip, windows the wavefront kernel does not take (k=7) and
+    frames too small for it (falls back to the LDS-tiled or the exact kernels).  Tolerance 1e-11 absolute on t."""
+    H, W = shape
+    rng = np.random.default_rng(100 * k + H)
+    B = 3
+    gray = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+    gray[1] = (np.add.outer(np.arange(H), np.arange(W)) % 256).astype(np.uint8)  # smooth ramp: tiny variances
+    t0 = rng.random((B, H, W), dtype=np.float32)
+    for eps in (0.5, 1e-3):
+        got = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), k, eps, exact=False).cpu().numpy()
+        for b in range(B):
+            want = np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], k, eps), 0.1, 1.0)
+            err = np.abs(got[b] - want).max()
+            assert err <= 1e-11, (k, shape, eps, b, err)
+
+
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
 def test_restore_matches_reference(dev, golden, tag):
     import torch

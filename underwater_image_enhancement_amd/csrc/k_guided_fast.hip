@@ -28,6 +28,8 @@
 #include "common.h"
 #include "devutil.h"
 
+#include <cstdlib>
+
 namespace uwie {
 
 namespace {
@@ -343,6 +345,11 @@ int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
                        hipStream_t st)
 {
     *handled = 0;
+    static const char *no_wave = getenv("UWIE_GF_NO_WAVE");
+    if (!no_wave) {
+        const int rcw = launch_guided_wave(d_gray, d_t0, s, k, eps, d_t, handled, st);
+        if (rcw != UWIE_OK || *handled) return rcw;
+    }
     const FastGeom g8 = make_fast_geom(s, k, 8), g4 = make_fast_geom(s, k, 4), g2 = make_fast_geom(s, k, 2);
     int rc = UWIE_OK;
     if (fits(g8, 8)) rc = launch_th<8>(d_gray, d_t0, s, g8, eps, d_t, st);
