@@ -101,3 +101,25 @@ def test_u8_over_255_identity():
         r = float(F(g) - F(q0) * 255)
         q1 = float(F(r) * F(rcp) + F(q0))
         assert q1 == g / 255.0, g
+
+
+def test_u8_over_255_identity_f32():
+    """devutil.h px_norm_fast: the float32 version of the same identity (used by the quadtree chunk sums)."""
+    from fractions import Fraction as F
+
+    import numpy as np
+
+    f32 = np.float32
+
+    def rn(fr):  # exact rational -> nearest float32, ties to even
+        y = f32(float(fr))
+        cands = [np.nextafter(y, f32(-np.inf)), y, np.nextafter(y, f32(np.inf))]
+        return min(cands, key=lambda c: (abs(F(float(c)) - fr), int(np.array([c], dtype=f32).view(np.uint32)[0]) & 1))
+
+    rcp = f32(1.0) / f32(255.0)
+    for u in range(256):
+        x = f32(u)
+        q0 = rn(F(float(x)) * F(float(rcp)))
+        r = rn(F(float(x)) - F(float(q0)) * 255)
+        q = rn(F(float(r)) * F(float(rcp)) + F(float(q0)))
+        assert q == f32(u) / f32(255.0), u

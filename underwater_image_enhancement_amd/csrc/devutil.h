@@ -12,6 +12,14 @@ constexpr int kWave = 64;
 // x = u8/255 (six_stadigy.py:406, true float32 division), then the cast attenuation of
 // color_correction (six_stadigy.py:310,317: channel * 0.85, clip is a no-op for values in [0,1]).
 __device__ __forceinline__ float px_norm(uint32_t u) { return (float)u / 255.0f; }
+// The same value without the division: q0 = u * fl(1/255), one Newton correction with two fmas.  Equal to the
+// correctly rounded u / 255.0f for every byte value (checked exhaustively in tests/test_cabi.py).
+__device__ __forceinline__ float px_norm_fast(uint32_t u)
+{
+    const float x = (float)u, rcp = 1.0f / 255.0f;
+    const float q0 = x * rcp;
+    return fmaf(fmaf(-q0, 255.0f, x), rcp, q0);
+}
 __device__ __forceinline__ float px_val(uint32_t u, bool attenuate)
 {
     float x = (float)u / 255.0f;

@@ -67,7 +67,7 @@ struct Elem {
     float mean[3];
     __device__ __forceinline__ float get(const uint8_t *p, int c) const
     {
-        float v = xs[p[c]];
+        float v = px_norm_fast(p[c]);
         if (px_atten(kind, c)) v = v * 0.85f;
         if (VAR) {
             const float d = v - mean[c];

@@ -10,15 +10,14 @@
 //                  6x8 gray neighbourhood in registers: separable Sobel on packed 16-bit pairs (v_pk_*), |dx|+|dy| for
 //                  the 4x6 magnitudes it needs (0 outside the region, like OpenCV's zero-padded magnitude rows/columns),
 //                  direction class and non-maximum suppression with OpenCV's fixed-point tan(22.5 deg) for its 8 pixels.
-//                  Writes the map byte {weak, none, strong} of every pixel and APPENDS the candidates (weak | strong) to
-//                  a list (one atomic per wavefront).
+//                  Writes the map byte {weak, none, strong} of every pixel and the candidates (weak | strong) of each
+//                  (tile, wavefront) into that wavefront's own list slot: no atomics, no second barrier.
 //   k_canny_union  8-connected components of the candidates: lock-free union-find on pixel indices (links always point
 //                  to the smaller index; agent-scope atomics, so XCD placement is irrelevant)
-//   k_canny_flat   pointer jumping: every candidate points at its root
-//   k_canny_mark   roots that own a strong pixel are flagged
+//   k_canny_mark   pointer jumping: every candidate points at its root; roots that own a strong pixel are flagged
 //   k_canny_emit   a candidate is an edge iff its root is flagged (= hysteresis); per-region edge counts, edge map
-// The component kernels walk the region's candidate list (grid-stride, length read on the device), not the frame:
-// smooth frames have few candidates.
+// The component kernels walk the candidate lists (one wavefront per tile), not the frame: smooth frames have few
+// candidates.
 // Hysteresis is order independent (an edge pixel is a weak-or-strong pixel whose 8-connected component holds a
 // strong one), so the component formulation equals OpenCV's stack-based flood fill.
 #include "common.h"
@@ -32,9 +31,9 @@ struct CannyBufs {
     uint8_t *cmap;     // 0 weak, 1 none, 2 strong
     int32_t *label;    // union-find parent (index inside the frame), candidates only
     uint8_t *flag;     // root owns a strong pixel, candidates only
-    uint32_t *cand;    // candidate lists, one segment of `seg` entries per region: pixel index inside the frame
-    uint32_t *ncand;   // their lengths
-    size_t seg;
+    uint32_t *cand;    // candidate lists: 512 entries per (tile, wavefront), pixel index inside the frame
+    uint32_t *ncand;   // their lengths, [tile][4]
+    int tiles;         // tiles per region in this launch
 };
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -62,14 +61,27 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     __shared__ __attribute__((aligned(8))) uint8_t sg[kSG_H][kSG_W];
     const Region r = regs[blockIdx.y];
     const int ty0 = (blockIdx.x / tiles_x) * kCT_H, tx0 = (blockIdx.x % tiles_x) * kCT_W;  // tile origin inside the region
-    if (ty0 >= r.rows || tx0 >= r.cols) return;
     const int tid = threadIdx.x;
+    const size_t sub = ((size_t)blockIdx.y * bufs.tiles + blockIdx.x) * 4 + (tid >> 6);  // this wavefront's list
+    if (ty0 >= r.rows || tx0 >= r.cols) {
+        if ((tid & 63) == 0) bufs.ncand[sub] = 0;
+        return;
+    }
     const size_t base = (size_t)r.img * H * W;
     const uint8_t *g = gray + base;
-    for (int i = tid; i < kSG_H * (kCT_W + 4); i += 256) {
-        const int ly = i / (kCT_W + 4), lx = i % (kCT_W + 4);
-        const int ry = min(max(ty0 + ly - 2, 0), r.rows - 1), rx = min(max(tx0 + lx - 2, 0), r.cols - 1);
-        sg[ly][lx] = g[(size_t)(r.y0 + ry) * W + r.x0 + rx];
+    if (tx0 >= 2 && tx0 + kCT_W + 2 <= r.cols) {  // no column clamping: (unaligned) dword loads, 17 per tile row
+        for (int i = tid; i < kSG_H * 17; i += 256) {
+            const int ly = i / 17, lq = i - ly * 17;
+            const int ry = min(max(ty0 + ly - 2, 0), r.rows - 1);
+            const uint8_t *src = g + (size_t)(r.y0 + ry) * W + r.x0 + tx0 - 2 + 4 * lq;
+            *reinterpret_cast<uint32_t *>(&sg[ly][4 * lq]) = *reinterpret_cast<const u32_unaligned *>(src);
+        }
+    } else {
+        for (int i = tid; i < kSG_H * (kCT_W + 4); i += 256) {
+            const int ly = i / (kCT_W + 4), lx = i % (kCT_W + 4);
+            const int ry = min(max(ty0 + ly - 2, 0), r.rows - 1), rx = min(max(tx0 + lx - 2, 0), r.cols - 1);
+            sg[ly][lx] = g[(size_t)(r.y0 + ry) * W + r.x0 + rx];
+        }
     }
     __syncthreads();
     const int cg = tid & 15, rp = tid >> 4;            // column group (4 pixels), row pair
@@ -87,11 +99,11 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
         hd[gr][0] = A1 - A0; hd[gr][1] = A2 - A1; hd[gr][2] = A3 - A2;
         vs[gr][0] = A0 + B0 + B0 + A1; vs[gr][1] = A1 + B1 + B1 + A2; vs[gr][2] = A2 + B2 + B2 + A3;
     }
+    // magnitudes outside the region are 0: only threads on the region border need the test
+    const bool border = ry0 < 1 || ry0 + 2 >= r.rows || rx0 < 1 || rx0 + 4 >= r.cols;
     int mag[4][6], cdx[2][4], cdy[2][4];
 #pragma unroll
     for (int mr = 0; mr < 4; ++mr) {
-        const int my = ry0 - 1 + mr;
-        const bool rowin = my >= 0 && my < r.rows;
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) {
             const v2s dx = hd[mr][pp] + hd[mr + 1][pp] + hd[mr + 1][pp] + hd[mr + 2][pp];
@@ -99,8 +111,8 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const v2s m = __builtin_elementwise_abs(dx) + __builtin_elementwise_abs(dy);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int mc = 2 * pp + h, mx = rx0 - 1 + mc;
-                mag[mr][mc] = (rowin && mx >= 0 && mx < r.cols) ? (int)(h ? m.y : m.x) : 0;
+                const int mc = 2 * pp + h;
+                mag[mr][mc] = (int)(h ? m.y : m.x);
                 if ((mr == 1 || mr == 2) && mc >= 1 && mc <= 4) {
                     cdx[mr - 1][mc - 1] = h ? dx.y : dx.x;
                     cdy[mr - 1][mc - 1] = h ? dy.y : dy.x;
@@ -108,33 +120,42 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             }
         }
     }
-    uint32_t ncand = 0, cls[2] = {0x01010101u, 0x01010101u};
-    uint32_t cpix[8];
+    if (border) {
+#pragma unroll
+        for (int mr = 0; mr < 4; ++mr) {
+            const int my = ry0 - 1 + mr;
+            const bool rowin = my >= 0 && my < r.rows;
+#pragma unroll
+            for (int mc = 0; mc < 6; ++mc) {
+                const int mx = rx0 - 1 + mc;
+                if (!(rowin && mx >= 0 && mx < r.cols)) mag[mr][mc] = 0;
+            }
+        }
+    }
+    // non-maximum suppression, branch-free: the two neighbours along the gradient direction are selected, not branched on
+    uint32_t cls[2] = {0x01010101u, 0x01010101u}, keepmask = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ry = ry0 + i, rx = rx0 + j;
-            if (!inside || ry >= r.rows || rx >= r.cols) continue;
             const int m = mag[i + 1][j + 1];
-            if (m <= low) continue;
             const int dx = cdx[i][j], dy = cdy[i][j];
             const int ax = abs(dx), ay = abs(dy) << 15;
             const int tg22x = ax * 13573;  // (int)(tan(22.5deg) * 2^15 + 0.5)
-            bool keep;
-            if (ay < tg22x) keep = m > mag[i + 1][j] && m >= mag[i + 1][j + 2];
-            else if (ay > tg22x + (ax << 16)) keep = m > mag[i][j + 1] && m >= mag[i + 2][j + 1];
-            else if ((dx ^ dy) < 0) keep = m > mag[i][j + 2] && m > mag[i + 2][j];
-            else keep = m > mag[i][j] && m > mag[i + 2][j + 2];
-            if (!keep) continue;
-            const uint32_t c = m > high ? 2u : 0u;
-            cls[i] = (cls[i] & ~(0xffu << (8 * j))) | (c << (8 * j));
-            const int p = (r.y0 + ry) * W + r.x0 + rx;
-            bufs.label[base + p] = p;
-            bufs.flag[base + p] = 0;
-            cpix[ncand++] = (uint32_t)p;
+            const bool isH = ay < tg22x, isV = ay > tg22x + (ax << 16), neg = (dx ^ dy) < 0;
+            const int d1 = neg ? mag[i][j + 2] : mag[i][j], d2 = neg ? mag[i + 2][j] : mag[i + 2][j + 2];
+            const int n1 = isH ? mag[i + 1][j] : isV ? mag[i][j + 1] : d1;
+            const int n2 = isH ? mag[i + 1][j + 2] : isV ? mag[i + 2][j + 1] : d2;
+            const bool diag = !isH && !isV;
+            const bool keep = inside && ry0 + i < r.rows && rx0 + j < r.cols && m > low && m > n1 &&
+                              (m > n2 || (!diag && m == n2));
+            if (keep) {
+                keepmask |= 1u << (4 * i + j);
+                cls[i] = (cls[i] & ~(0xffu << (8 * j))) | ((m > high ? 2u : 0u) << (8 * j));
+            }
         }
     }
+    const uint32_t ncand = __popc(keepmask);
     // map bytes: one (unaligned) dword per row when the 4 pixels exist, else byte by byte
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -144,22 +165,18 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
         else
             for (int j = 0; j < r.cols - rx0; ++j) dst[j] = (uint8_t)(cls[i] >> (8 * j));
     }
-    // candidate list of this region: one global atomic per workgroup (a single list-wide counter serialises in L2)
-    __shared__ uint32_t blk_n, blk_base;
-    if (tid == 0) blk_n = 0;
-    __syncthreads();
-    const uint32_t incl = wave_incl_scan_u32(ncand), total = __shfl(incl, 63);
-    uint32_t wbase = 0;
-    if ((tid & 63) == 63 && total) wbase = atomicAdd(&blk_n, total);
-    wbase = __shfl(wbase, 63);
-    __syncthreads();
-    if (tid == 0 && blk_n) blk_base = atomicAdd(bufs.ncand + blockIdx.y, blk_n);
-    __syncthreads();
+    // candidate list of this (tile, wavefront): fixed slot, so no atomics and nothing to wait for
+    const uint32_t incl = wave_incl_scan_u32(ncand);
+    if ((tid & 63) == 63) bufs.ncand[sub] = incl;
     if (ncand) {
-        uint32_t *dst = bufs.cand + (size_t)blockIdx.y * bufs.seg + blk_base + wbase + (incl - ncand);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < (int)ncand) dst[k] = cpix[k];
+        uint32_t *dst = bufs.cand + sub * 512 + (incl - ncand);
+        for (uint32_t km = keepmask; km; km &= km - 1) {
+            const int b = __ffs(km) - 1;
+            const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
+            bufs.label[base + p] = p;
+            bufs.flag[base + p] = 0;
+            *dst++ = (uint32_t)p;
+        }
     }
 }
 
@@ -194,12 +211,33 @@ __device__ void uf_union(int32_t *L, int a, int b)
     }
 }
 
-// grid-stride walk of the candidate list of region blockIdx.y
-#define UWIE_FOR_CANDIDATES(p)                                                                          \
-    const uint32_t n_cand = bufs.ncand[blockIdx.y];                                                     \
-    const uint32_t *cand = bufs.cand + (size_t)blockIdx.y * bufs.seg;                                   \
-    for (uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x; ci < n_cand; ci += gridDim.x * blockDim.x) \
-        if (const int p = (int)cand[ci]; true)
+// List walkers: one wavefront takes 16 tiles (64 lists) of region blockIdx.y, loads the 64 lengths with one load and
+// spreads ALL their entries over its lanes (entry idx -> list by a binary search over the prefix sums, via shuffles),
+// so lanes stay busy however unevenly the candidates are spread.
+constexpr int kWalkTiles = 16;
+
+template <class F>
+__device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kWalkTiles;
+    if (tile0 >= bufs.tiles) return;  // wavefront-uniform
+    const size_t sub0 = ((size_t)blockIdx.y * bufs.tiles + tile0) * 4;
+    const int nsub = min(64, (bufs.tiles - tile0) * 4);
+    const uint32_t cnt = lane < nsub ? bufs.ncand[sub0 + lane] : 0;
+    const uint32_t incl = wave_incl_scan_u32(cnt), excl = incl - cnt, total = __shfl(incl, 63);
+    for (uint32_t b0 = 0; b0 < total; b0 += 64) {
+        const uint32_t idx = b0 + lane;
+        int sl = 0;  // largest list index whose exclusive prefix is <= idx
+#pragma unroll
+        for (int step = 32; step; step >>= 1) {
+            const uint32_t e = __shfl(excl, sl + step);  // sl + step <= 63
+            if (e <= idx) sl += step;
+        }
+        const uint32_t off = idx - __shfl(excl, sl);
+        if (idx < total) f((int)bufs.cand[(sub0 + sl) * 512 + off]);
+    }
+}
 
 __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
@@ -207,8 +245,7 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
     const size_t base = (size_t)r.img * H * W;
     const uint8_t *cm = bufs.cmap + base;
     int32_t *L = bufs.label + base;
-    UWIE_FOR_CANDIDATES(p)
-    {
+    for_candidates(bufs, [&](int p) {
         const int y = p / W, x = p - y * W;
         const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
         if (right && cm[p + 1] != 1) uf_union(L, p, p + 1);
@@ -217,14 +254,15 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
             if (cm[p + W] != 1) uf_union(L, p, p + W);
             if (right && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
         }
-    }
+    });
 }
 
-__global__ void __launch_bounds__(256) k_canny_flat(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
+// every candidate points at its root; roots that own a strong pixel are flagged
+__global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
-    int32_t *L = bufs.label + (size_t)regs[blockIdx.y].img * H * W;
-    UWIE_FOR_CANDIDATES(p)
-    {
+    const size_t base = (size_t)regs[blockIdx.y].img * H * W;
+    int32_t *L = bufs.label + base;
+    for_candidates(bufs, [&](int p) {
         int root = p;
         for (;;) {
             const int q = ld_label(L, root);
@@ -232,20 +270,8 @@ __global__ void __launch_bounds__(256) k_canny_flat(const Region *__restrict__ r
             root = q;
         }
         if (root != p) atomicMin(L + p, root);
-    }
-}
-
-__global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
-{
-    const size_t base = (size_t)regs[blockIdx.y].img * H * W;
-    const int32_t *L = bufs.label + base;
-    UWIE_FOR_CANDIDATES(p)
-    {
-        if (bufs.cmap[base + p] != 2) continue;
-        int root = p;
-        while (L[root] != root) root = L[root];
-        bufs.flag[base + root] = 1;
-    }
+        if (bufs.cmap[base + p] == 2) bufs.flag[base + root] = 1;
+    });
 }
 
 __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
@@ -254,15 +280,14 @@ __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ r
     const size_t base = (size_t)regs[blockIdx.y].img * H * W;
     const int32_t *L = bufs.label + base;
     uint32_t mine = 0;
-    UWIE_FOR_CANDIDATES(p)
-    {
+    for_candidates(bufs, [&](int p) {
         int root = p;
         while (L[root] != root) root = L[root];
         if (bufs.flag[base + root]) {
             ++mine;
             if (edges) edges[base + p] = 255;
         }
-    }
+    });
     if (count) {
         const uint32_t tot = wave_sum_u32(mine);
         if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + blockIdx.y, tot);
@@ -275,8 +300,13 @@ __global__ void k_full_regions(Region *regs, int B, int H, int W)
     if (b < B) regs[b] = Region{b, 0, 0, H, W};
 }
 
-// The largest launches are one region per frame (H x W) and four quadrants per frame (ceil(H/2) x ceil(W/2) each).
-size_t canny_list_entries(Shape s) { return (size_t)4 * s.B * ((s.H + 1) / 2) * ((s.W + 1) / 2); }
+// Tiles of the largest launches: one region per frame (H x W), or four quadrants per frame (ceil(H/2) x ceil(W/2) each).
+size_t canny_list_tiles(Shape s)
+{
+    const size_t full = (size_t)cdiv(s.H, kCT_H) * cdiv(s.W, kCT_W);
+    const size_t quad = (size_t)4 * cdiv((s.H + 1) / 2, kCT_H) * cdiv((s.W + 1) / 2, kCT_W);
+    return (size_t)s.B * std::max(full, quad);
+}
 
 CannyBufs carve_canny(Carver &c, Shape s)
 {
@@ -285,9 +315,9 @@ CannyBufs carve_canny(Carver &c, Shape s)
     b.cmap = c.take<uint8_t>(n);
     b.label = c.take<int32_t>(n);
     b.flag = c.take<uint8_t>(n);
-    b.seg = 0;  // set per launch
-    b.cand = c.take<uint32_t>(canny_list_entries(s));
-    b.ncand = c.take<uint32_t>((size_t)4 * s.B);
+    b.tiles = 0;  // set per launch
+    b.cand = c.take<uint32_t>(canny_list_tiles(s) * 2048);
+    b.ncand = c.take<uint32_t>(canny_list_tiles(s) * 4);
     return b;
 }
 
@@ -314,21 +344,17 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     CannyBufs bufs = carve_canny(c, s);
     const int tiles_x = cdiv(max_cols, kCT_W), tiles_y = cdiv(max_rows, kCT_H);
     const dim3 tgrid(tiles_x * tiles_y, nreg), block(256);
-    bufs.seg = (size_t)max_rows * max_cols;
-    if (nreg > 4 * s.B || (size_t)nreg * bufs.seg > canny_list_entries(s)) {
+    bufs.tiles = tiles_x * tiles_y;
+    if ((size_t)nreg * bufs.tiles > canny_list_tiles(s)) {
         set_error("canny: %d regions of %d x %d exceed the candidate-list workspace", nreg, max_rows, max_cols);
         return UWIE_E_INVALID;
     }
-    // list walkers: a few blocks per region (grid-stride), at most one thread per possible candidate
-    const dim3 lgrid((unsigned)std::min<size_t>(cdiv(bufs.seg, (size_t)256), (size_t)std::max(8, 4096 / nreg)), nreg);
+    const dim3 lgrid(cdiv(cdiv(bufs.tiles, kWalkTiles), 4), nreg);  // list walkers: 4 wavefronts per block
     if (d_count) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
-    UWIE_HIP_CHECK(hipMemsetAsync(bufs.ncand, 0, sizeof(uint32_t) * nreg, st));
     UWIE_LAUNCH(k_canny_gradnms, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_canny_union, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
-    UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_canny_flat, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_canny_mark, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
