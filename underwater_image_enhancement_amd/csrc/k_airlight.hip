@@ -17,7 +17,8 @@ namespace uwie {
 namespace {
 
 constexpr int kNpChunk = 8192;  // NumPy's reduction buffer size (np.getbufsize())
-constexpr int kMaxLeaves = 192;
+constexpr int kMaxLeaves = 192;   // a leaf of the pairwise recursion holds 64..128 elements: at most 127 per 8192-element chunk
+constexpr int kTreeLevels = 10;    // depth of that recursion for n < 8192 is at most 8
 constexpr int kMaxLevels = 32;
 
 struct TraceRec {  // matches the layout documented in uwie.h
@@ -203,10 +204,9 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     const int len = min(kNpChunk, n - c0);
 
     __shared__ float xs[256];
-    __shared__ int leafOff[kMaxLeaves], leafLen[kMaxLeaves], nLeaf;
-    __shared__ float leafSum[3][kMaxLeaves];
-    __shared__ int fOff[32], fLen[32], fStage[32];
-    __shared__ float vals[3][32];
+    __shared__ uint16_t lvOff[kTreeLevels + 1][kMaxLeaves], lvLen[kTreeLevels + 1][kMaxLeaves], lvChild[kTreeLevels][kMaxLeaves];
+    __shared__ int lvCnt[kTreeLevels + 1];
+    __shared__ float val[2][3][kMaxLeaves];
     for (int i = lane; i < 256; i += 64) xs[i] = px_norm(i);
     __syncthreads();
 
@@ -235,59 +235,64 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
         if (lane == 0) { out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; }
         return;
     }
-    // ragged chunk: enumerate the recursion's leaves (pre-order == left-to-right order)
-    if (lane == 0) {
-        int sp = 0, nl = 0;
-        fOff[0] = 0; fLen[0] = len; sp = 1;
-        while (sp > 0) {
-            --sp;
-            const int off = fOff[sp], l = fLen[sp];
-            if (l <= 128) {
-                leafOff[nl] = off; leafLen[nl] = l; ++nl;
-            } else {
-                int n2 = l / 2;
-                n2 -= n2 % 8;
-                fOff[sp] = off + n2; fLen[sp] = l - n2; ++sp;  // right child (popped second)
-                fOff[sp] = off; fLen[sp] = n2; ++sp;           // left child (popped first)
-            }
-        }
-        nLeaf = nl;
-    }
+    // Ragged chunk: NumPy's recursion splits n > 128 into n2 = n/2 - (n/2)%8 and n - n2.  The tree is expanded level by
+    // level with every lane working (a node list per level, kept in left-to-right order: a split node is replaced by
+    // its two children in place), leaves are summed one per lane, and the sums are folded back level by level
+    // (value = left + right, as the recursion returns them).
+    int nlev = 0;
+    if (lane == 0) { lvOff[0][0] = 0; lvLen[0][0] = (uint16_t)len; lvCnt[0] = 1; }
     __syncthreads();
+    for (;;) {
+        const int cnt = lvCnt[nlev];
+        int carry = 0;
+        bool any = false;
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+            const int i = b0 + lane;
+            const int l = i < cnt ? lvLen[nlev][i] : 0, off = i < cnt ? lvOff[nlev][i] : 0;
+            const bool split = l > 128;
+            const uint32_t kids = i < cnt ? (split ? 2u : 1u) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(kids);
+            const int pos = carry + (int)(incl - kids);
+            if (i < cnt) {
+                lvChild[nlev][i] = (uint16_t)pos;
+                if (split) {
+                    int n2 = l / 2;
+                    n2 -= n2 % 8;
+                    lvOff[nlev + 1][pos] = (uint16_t)off; lvLen[nlev + 1][pos] = (uint16_t)n2;
+                    lvOff[nlev + 1][pos + 1] = (uint16_t)(off + n2); lvLen[nlev + 1][pos + 1] = (uint16_t)(l - n2);
+                } else {
+                    lvOff[nlev + 1][pos] = (uint16_t)off; lvLen[nlev + 1][pos] = (uint16_t)l;
+                }
+            }
+            carry += (int)__shfl(incl, 63);
+            any = any || __any(split);
+        }
+        if (!any) break;  // level `nlev` holds only leaves
+        if (lane == 0) lvCnt[nlev + 1] = carry;
+        ++nlev;
+        __syncthreads();
+    }
+    const int nLeaf = lvCnt[nlev];
     for (int i = lane; i < nLeaf; i += 64) {
         float s[3];
-        leaf_sum3<VAR>(el, r, c0 + leafOff[i], leafLen[i], s);
-        leafSum[0][i] = s[0]; leafSum[1][i] = s[1]; leafSum[2][i] = s[2];
+        leaf_sum3<VAR>(el, r, c0 + lvOff[nlev][i], lvLen[nlev][i], s);
+        val[nlev & 1][0][i] = s[0]; val[nlev & 1][1][i] = s[1]; val[nlev & 1][2][i] = s[2];
     }
     __syncthreads();
-    // post-order combine, replaying the recursion; lanes 0..2 each own one channel's value stack,
-    // lane 0's frame stack drives all three (the tree shape does not depend on the channel)
-    if (lane == 0) {
-        int sp = 0, vsp = 0, next = 0;
-        fOff[0] = 0; fLen[0] = len; fStage[0] = 0; sp = 1;
-        while (sp > 0) {
-            const int t = sp - 1, l = fLen[t];
-            if (l <= 128) {
-                vals[0][vsp] = leafSum[0][next]; vals[1][vsp] = leafSum[1][next]; vals[2][vsp] = leafSum[2][next];
-                ++vsp; ++next; --sp;
-                continue;
-            }
-            int n2 = l / 2;
-            n2 -= n2 % 8;
-            if (fStage[t] == 0) {
-                fStage[t] = 1;
-                fOff[sp] = fOff[t]; fLen[sp] = n2; fStage[sp] = 0; ++sp;
-            } else if (fStage[t] == 1) {
-                fStage[t] = 2;
-                fOff[sp] = fOff[t] + n2; fLen[sp] = l - n2; fStage[sp] = 0; ++sp;
-            } else {
-                --vsp;
-                for (int c = 0; c < 3; ++c) vals[c][vsp - 1] = vals[c][vsp - 1] + vals[c][vsp];
-                --sp;
+    for (int lv = nlev - 1; lv >= 0; --lv) {
+        const int cnt = lvCnt[lv];
+        for (int i = lane; i < cnt; i += 64) {
+            const int ch = lvChild[lv][i];
+            const bool split = lvLen[lv][i] > 128;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = val[(lv + 1) & 1][c][ch];
+                val[lv & 1][c][i] = split ? a + val[(lv + 1) & 1][c][ch + 1] : a;
             }
         }
-        out[0] = vals[0][0]; out[1] = vals[1][0]; out[2] = vals[2][0];
+        __syncthreads();
     }
+    if (lane == 0) { out[0] = val[0][0][0]; out[1] = val[0][1][0]; out[2] = val[0][2][0]; }
 }
 
 // Sequential accumulation of the chunk sums (NumPy adds each buffer's pairwise result into the running total),
