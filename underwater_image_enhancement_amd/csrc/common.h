@@ -44,6 +44,7 @@ struct LabTables {           // OpenCV's integer sRGB<->Lab tables (see tables.c
 struct CastTables {                         // rounding tables for the sequential float32 mean (k_entry.hip)
     uint32_t R[kCastBinades][256];          // RN(x_k / ulp_e)
     uint8_t tie[kCastBinades][256];         // 1 if x_k / ulp_e has fractional part exactly 1/2
+    uint32_t RT[256][kCastBinades];         // R transposed, tie in bit 31 (R < 2^26): one coalesced row per value
 };
 
 void build_lab_tables(LabTables *t);

@@ -9,10 +9,11 @@
 //     of pixels advances s by an INTEGER number of ulps that depends only on the histogram of the run
 //     (inputs are u8/255: 256 distinct values);
 //   * k_chunk_hist writes one 3x256 histogram per 16384-pixel chunk (one streaming pass over the frame);
-//   * k_cast_resolve (one wavefront per image and channel) walks the chunks, advancing s in closed form
-//     while the chunk stays inside the binade and has no round-half-even tie, and otherwise drills into
-//     the chunk: 64 lanes x 256-pixel runs, a wave prefix scan to find the run that crosses the binade,
-//     and plain sequential float adds inside that one run.
+//   * k_chunk_ulps turns each chunk histogram into its ulp advance for every binade of the accumulator;
+//   * k_cast_resolve (one wavefront per image and channel) walks the chunks 64 at a time: a prefix scan over
+//     their ulp advances finds the first chunk that leaves the binade or holds a round-half-even tie, s jumps
+//     there in closed form, and that chunk is drilled: 64 lanes x 256-pixel runs, the same scan, then 64 x 4
+//     pixels, and plain sequential float adds only for the last 4 pixels around the event.
 #include "common.h"
 #include "devutil.h"
 
@@ -52,96 +53,161 @@ __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
     return __uint_as_float(((uint32_t)(e + 127) << 23) | (S & 0x7fffffu));
 }
 
+// Per chunk, channel and binade e of the accumulator: the number of ulps the chunk advances it by,
+// D = sum_k hist[k] * RN(x_k / ulp_e), with bit 63 set when some present value ties (x_k / ulp_e = n + 1/2: the result
+// then depends on the parity of the running sum and the chunk has to be walked).  One thread per (channel, binade).
+constexpr uint64_t kTieBit = 1ull << 63;
+
+__global__ void __launch_bounds__(128) k_chunk_ulps(const uint32_t *__restrict__ hist, const CastTables *__restrict__ tab,
+                                                    int nchunk, uint64_t *__restrict__ ulps)
+{
+    __shared__ uint32_t h[768];
+    const size_t chunk = (size_t)blockIdx.y * nchunk + blockIdx.x;
+    for (int i = threadIdx.x; i < 768; i += 128) h[i] = hist[chunk * 768 + i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 3 * kCastBinades) return;
+    const int ch = t / kCastBinades, ei = t - ch * kCastBinades;
+    uint64_t D = 0;
+    uint32_t tie = 0;
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) {
+        const uint32_t n = h[ch * 256 + k], rt = tab->RT[k][ei];  // threads of one channel read one 136-byte row
+        D += (uint64_t)n * (rt & 0x7fffffffu);
+        tie |= n ? rt >> 31 : 0u;
+    }
+    ulps[(chunk * 3 + ch) * kCastBinades + ei] = D | (tie ? kTieBit : 0);
+}
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
 // Advance the accumulator `s` over pixels [p0, p0+cnt) of one channel (stride 3 bytes); all 64 lanes call.
-__device__ float drill_chunk(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab,
-                             const float *xs)
+// Lanes take `per` consecutive pixels each.  One pass over the pixels gives every lane its ulp advance for the current
+// binade e AND for e+1 (the table rows of both sit in LDS), so the pixels are read once per call: a prefix scan finds the
+// first lane whose pixels leave the binade or tie, s jumps there in closed form, that lane's pixels are split 64 ways
+// again (per -> per/64, last level: 4 pixels added one by one), and the scan resumes behind it with the row of the binade
+// s is in by then.
+template <int per>
+__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, uint2 *row)
 {
     const int lane = threadIdx.x & 63;
-    const int ln = max(0, min(kRunPx, cnt - lane * kRunPx));
-    const uint8_t *run = chan + (size_t)(p0 + lane * kRunPx) * 3;
+    const int ln = max(0, min(per, cnt - lane * per));
+    const uint8_t *run = chan + (size_t)(p0 + lane * per) * 3;
     int first = 0;
     while (first < kWave) {
-        int L;  // the run that has to be walked one pixel at a time
+        int L;  // the lane whose pixels have to be looked at more closely
         if (s >= 0.25f) {
             const int e = (int)(__float_as_uint(s) >> 23) - 127;
-            const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
-            uint64_t D = 0;
-            uint32_t T = 0;
-            if (lane >= first)
-                for (int i = 0; i < ln; ++i) {
-                    const uint32_t u = run[(size_t)i * 3];
-                    D += tab->R[ei][u];
-                    T += tab->tie[ei][u];
+            const int ei = min(e - kCastBinadeMin, kCastBinades - 1), ei1 = min(ei + 1, kCastBinades - 1);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < 256; k += 64) row[k] = make_uint2(tab->RT[k][ei], tab->RT[k][ei1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint64_t D[2] = {0, 0};
+            uint32_t T[2] = {0, 0};
+            auto add = [&](uint32_t u) {
+                const uint2 v = row[u];
+                D[0] += v.x & 0x7fffffffu; T[0] |= v.x >> 31;
+                D[1] += v.y & 0x7fffffffu; T[1] |= v.y >> 31;
+            };
+            if (lane >= first) {
+                int i = 0;
+                if constexpr (per >= 64) {
+                    // 16 pixels = 48 bytes = 12 (unaligned) dwords per step, all loads of a step in flight together
+                    for (; i + 17 <= ln; i += 16) {  // (the 12th dword reaches 2 bytes past pixel i+15: keep one pixel behind it)
+                        const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(run + (size_t)i * 3);
+                        uint32_t d[12];
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) d[q] = w[q];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int byte = 3 * q;
+                            add((d[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                        }
+                    }
                 }
-            const uint64_t incl = wave_incl_scan_u64(D);
-            const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
-            const bool bad = lane >= first && (T != 0 || S + incl >= (1ull << 24));
-            const uint64_t mask = __ballot(bad);
-            L = mask ? (int)__builtin_ctzll(mask) : kWave;
-            const uint64_t adv = L > first ? shfl_u64(incl, L - 1) : 0;
-            s = from_mantissa(S + (uint32_t)adv, e);
-        } else {
-            // tiny accumulator: skip runs that are all zero (adding 0.0f changes nothing), walk the first that is not
-            bool nz = false;
-            if (lane >= first)
-                for (int i = 0; i < ln; ++i) nz |= run[(size_t)i * 3] != 0;
-            const uint64_t mask = __ballot(nz);
-            L = mask ? (int)__builtin_ctzll(mask) : kWave;
+                for (; i < ln; ++i) add(run[(size_t)i * 3]);
+            }
+            // events inside this pass: as long as s stays in e or e+1 the lane sums above remain valid
+            for (;;) {
+                const int ec = (int)(__float_as_uint(s) >> 23) - 127;
+                if (ec != e && !(ec == e + 1 && ei1 == ei + 1)) { L = -1; break; }  // another binade: new pass
+                const int w = ec - e;
+                const uint64_t incl = wave_incl_scan_u64(lane >= first ? D[w] : 0);
+                const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
+                const bool bad = lane >= first && (T[w] != 0 || S + incl >= (1ull << 24));
+                const uint64_t mask = __ballot(bad);
+                L = mask ? (int)__builtin_ctzll(mask) : kWave;
+                const uint64_t adv = L > first ? shfl_u64(incl, L - 1) : 0;
+                s = from_mantissa(S + (uint32_t)adv, ec);
+                if (L >= kWave) break;
+                const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));  // wavefront-uniform
+                if constexpr (per > 4) {
+                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256);
+                } else {
+                    if (lane == 0)
+                        for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
+                    s = __shfl(s, 0);
+                }
+                first = L + 1;
+                if (first >= kWave) break;
+            }
+            if (L < 0) continue;
+            break;  // L >= kWave or every lane consumed
         }
+        // tiny accumulator: skip lanes whose pixels are all zero (adding 0.0f changes nothing)
+        bool nz = false;
+        if (lane >= first)
+            for (int i = 0; i < ln; ++i) nz |= run[(size_t)i * 3] != 0;
+        const uint64_t mask = __ballot(nz);
+        L = mask ? (int)__builtin_ctzll(mask) : kWave;
         if (L >= kWave) break;
-        if (lane == L)
-            for (int i = 0; i < ln; ++i) s = s + xs[run[(size_t)i * 3]];
-        s = __shfl(s, L);
+        const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));
+        if constexpr (per > 4) {
+            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256);
+        } else {
+            if (lane == 0)
+                for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
+            s = __shfl(s, 0);
+        }
         first = L + 1;
     }
     return s;
 }
 
-__global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__ in, const uint32_t *__restrict__ hist,
+// One wavefront per (image, channel): 64 chunks per step.  Lane j holds the ulp count of chunk c+j for the current
+// binade; a prefix scan finds the first chunk that leaves the binade or ties, s jumps to that chunk in closed form,
+// the chunk is drilled, and the walk resumes behind it (a binade is left ~24 times per channel at 4K).
+__global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__ in, const uint64_t *__restrict__ ulps,
                                                      const CastTables *__restrict__ tab, int npx, int nchunk,
                                                      float *__restrict__ sums)
 {
+    __shared__ uint2 row[2][256];  // table rows of the two binades in play, one set per drill level
     const int ch = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    __shared__ float xs[256];
-    for (int i = lane; i < 256; i += 64) xs[i] = px_norm(i);
-    __syncthreads();
     const uint8_t *chan = in + (size_t)b * npx * 3 + ch;
+    const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
     float s = 0.0f;
-    // The only loop-carried value is s.  Everything that does not depend on it is kept off the critical path: the
-    // next chunk's histogram slice is prefetched, and the rounding-table row of the current binade stays in registers
-    // (it changes ~24 times per channel).
-    const uint4 *hp = reinterpret_cast<const uint4 *>(hist + (((size_t)b * nchunk) * 3 + ch) * 256 + lane * 4);
-    uint4 hnext = hp[0];
-    int ei_cached = -1;
-    uint32_t R0 = 0, R1 = 0, R2 = 0, R3 = 0;
-    bool t0 = false, t1 = false, t2 = false, t3 = false;
-    for (int c = 0; c < nchunk; ++c) {
-        const uint4 hv = hnext;
-        if (c + 1 < nchunk) hnext = hp[(size_t)(c + 1) * 192];  // 768 words per chunk = 192 uint4
-        const uint32_t h0 = hv.x, h1 = hv.y, h2 = hv.z, h3 = hv.w;
-        bool done;
+    int c = 0;
+    while (c < nchunk) {
+        int L = 0;  // chunks passed in closed form
         if (s >= 0.25f) {
             const int e = (int)(__float_as_uint(s) >> 23) - 127;
             const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
-            if (ei != ei_cached) {
-                const uint32_t *R = &tab->R[ei][lane * 4];
-                const uint8_t *Tt = &tab->tie[ei][lane * 4];
-                R0 = R[0]; R1 = R[1]; R2 = R[2]; R3 = R[3];
-                t0 = Tt[0] != 0; t1 = Tt[1] != 0; t2 = Tt[2] != 0; t3 = Tt[3] != 0;
-                ei_cached = ei;
-            }
-            uint64_t D = (uint64_t)h0 * R0 + (uint64_t)h1 * R1 + (uint64_t)h2 * R2 + (uint64_t)h3 * R3;
-            uint32_t T = (h0 && t0) + (h1 && t1) + (h2 && t2) + (h3 && t3);
-            D = wave_sum_u64(D);
-            T = wave_sum_u32(T);
+            const bool have = c + lane < nchunk;
+            const uint64_t v = have ? u[(size_t)(c + lane) * 3 * kCastBinades + ei] : kTieBit;
+            const uint64_t incl = wave_incl_scan_u64(v & ~kTieBit);
             const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
-            done = T == 0 && S + D < (1ull << 24);
-            if (done) s = from_mantissa(S + (uint32_t)D, e);
-        } else {
-            const uint32_t nz = wave_sum_u32((lane == 0 ? 0u : h0) + h1 + h2 + h3);
-            done = nz == 0;
+            const bool bad = (v & kTieBit) || S + incl >= (1ull << 24);
+            const uint64_t mask = __ballot(bad);
+            L = mask ? (int)__builtin_ctzll(mask) : kWave;
+            const uint64_t adv = L > 0 ? shfl_u64(incl, L - 1) : 0;
+            s = from_mantissa(S + (uint32_t)adv, e);
+            c += L;
+            if (L == kWave || c >= nchunk) continue;
         }
-        if (!done) s = drill_chunk(chan, c * kChunkPx, min(kChunkPx, npx - c * kChunkPx), s, tab, xs);
+        s = drill<kRunPx>(chan, c * kChunkPx, min(kChunkPx, npx - c * kChunkPx), s, tab, &row[0][0]);
+        ++c;
     }
     if (lane == 0) sums[b * 3 + ch] = s;
 }
@@ -172,6 +238,7 @@ size_t cast_ws_bytes(Shape s)
     Carver c(nullptr);
     const int nchunk = cdiv((long long)s.npx(), kChunkPx);
     c.take<uint32_t>((size_t)s.B * nchunk * 768);
+    c.take<uint64_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     c.take<float>((size_t)s.B * 3);
     return c.total();
 }
@@ -183,10 +250,13 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     const int npx = (int)s.npx();
     const int nchunk = cdiv(npx, kChunkPx);
     uint32_t *hist = c.take<uint32_t>((size_t)s.B * nchunk * 768);
+    uint64_t *ulps = c.take<uint64_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     float *sums = c.take<float>((size_t)s.B * 3);
     UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, hist, npx, nchunk);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, hist, ctx->d_cast, npx, nchunk, sums);
+    UWIE_LAUNCH(k_chunk_ulps, dim3(nchunk, s.B), dim3(128), 0, st, hist, ctx->d_cast, nchunk, ulps);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, ulps, ctx->d_cast, npx, nchunk, sums);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_cast_decide, dim3(cdiv(s.B, 64)), dim3(64), 0, st, sums, s.B, npx, d_kind, d_mean);
     UWIE_LAUNCH_CHECK();

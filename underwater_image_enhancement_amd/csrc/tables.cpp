@@ -124,6 +124,7 @@ void build_cast_tables(CastTables *t)
             }
             t->R[ei][k] = (uint32_t)R;
             t->tie[ei][k] = tie;
+            t->RT[k][ei] = (uint32_t)R | (tie ? 0x80000000u : 0u);
         }
     }
 }
