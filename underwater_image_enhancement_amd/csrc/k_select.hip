@@ -91,10 +91,17 @@ __device__ __forceinline__ void sel_count(uint32_t *h, V v, int shift, int bits,
     if (first_pass) {
         atomicAdd(&h[d], 1u);
     } else {
+        // prefixes of distinct groups differ, so at most one matches: select its index, then one conditional atomic
+        // (gp[g] for g >= ng holds a value no prefix can take, see k_sel_hist)
         const K pre = key >> (shift + bits);
+        uint32_t idx = 0xffffffffu;
 #pragma unroll
-        for (int g = 0; g < kMaxRanks; ++g)
-            if (g < ng && pre == gp[g]) atomicAdd(&h[g * nbins + d], 1u);
+        for (int g = 0; g < 4; ++g) idx = pre == gp[g] ? (uint32_t)g : idx;
+        if (ng > 4) {
+#pragma unroll
+            for (int g = 4; g < kMaxRanks; ++g) idx = pre == gp[g] ? (uint32_t)g : idx;
+        }
+        if (idx != 0xffffffffu) atomicAdd(&h[idx * nbins + d], 1u);
     }
 }
 
@@ -114,7 +121,7 @@ __global__ void __launch_bounds__(256) k_sel_hist(const V *__restrict__ vals, si
     const int ng = first_pass ? 1 : min((int)s->ngroups, ng_cap);
     K gp[kMaxRanks];
 #pragma unroll
-    for (int g = 0; g < kMaxRanks; ++g) gp[g] = s->gprefix[g];
+    for (int g = 0; g < kMaxRanks; ++g) gp[g] = g < ng ? s->gprefix[g] : ~K(0);  // ~0 >> (shift + bits) is not a prefix
     for (int i = threadIdx.x; i < ng * nbins; i += 256) h[i] = 0;
     __syncthreads();
     const V *v = vals + (size_t)(bc / 3) * img_stride + (size_t)(bc % 3) * chan_stride;
@@ -123,7 +130,21 @@ __global__ void __launch_bounds__(256) k_sel_hist(const V *__restrict__ vals, si
     const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);                 // lo == hi for surplus blocks
     if (elem_stride == 1 && ((size_t)v & 15) == 0) {
         const int hiv = lo + ((hi - lo) / VEC) * VEC;
-        for (int i = lo + threadIdx.x * VEC; i < hiv; i += 256 * VEC) {
+        constexpr int U = 4;  // 16-byte loads in flight per thread: the sweep is latency-bound, not compute-bound
+        int i = lo + threadIdx.x * VEC;
+        for (; i + (U - 1) * 256 * VEC < hiv; i += U * 256 * VEC) {
+            uint4 raw[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) raw[u] = *reinterpret_cast<const uint4 *>(v + i + u * 256 * VEC);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                V q[VEC];
+                *reinterpret_cast<uint4 *>(q) = raw[u];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sel_count<V>(h, q[j], shift, bits, mask, first_pass, ng, nbins, gp);
+            }
+        }
+        for (; i < hiv; i += 256 * VEC) {
             V q[VEC];
             *reinterpret_cast<uint4 *>(q) = *reinterpret_cast<const uint4 *>(v + i);
 #pragma unroll
