@@ -36,6 +36,18 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
     const bool aligned = (npx & 3) == 0;
     const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
     const double *trow = t + (size_t)b * npx;
+    // The first digit (sign, exponent, 2 mantissa bits) takes a dozen values on a whole frame, so plain LDS atomics
+    // serialise 64 deep.  Each thread counts runs of equal digits in registers and touches LDS only when the digit
+    // changes (neighbouring pixels almost always share it).
+    uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0};
+    auto bump = [&](int c, uint32_t d) {
+        if (d != cur[c]) {
+            if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
+            cur[c] = d;
+            run[c] = 0;
+        }
+        ++run[c];
+    };
     for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
         const int n = min(4, npx - p);
         const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
@@ -56,9 +68,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
             r1[i] = clip01((float)((double)d1 / tv[i] + (double)a1));
             r2[i] = clip01((float)((double)d2 / tv[i] + (double)a2));
             if (i < n) {
-                atomicAdd(&h[0][f32_key(r0[i]) >> 21], 1u);
-                atomicAdd(&h[1][f32_key(r1[i]) >> 21], 1u);
-                atomicAdd(&h[2][f32_key(r2[i]) >> 21], 1u);
+                bump(0, f32_key(r0[i]) >> 21);
+                bump(1, f32_key(r1[i]) >> 21);
+                bump(2, f32_key(r2[i]) >> 21);
             }
         }
         if (aligned && n == 4) {
@@ -73,6 +85,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
             }
         }
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
     __syncthreads();
     for (int i = tid; i < 3 * 2048; i += 256) {
         const uint32_t c = (&h[0][0])[i];
