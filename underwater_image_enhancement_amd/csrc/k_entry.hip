@@ -298,20 +298,27 @@ int launch_normalise_correct(const uint8_t *d_in, const int32_t *d_kind, float *
 __global__ void __launch_bounds__(256) k_quant_gray(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                     uint8_t *__restrict__ gray, int npx, int shift)
 {
+    // (x * 255).astype(u8) of the (colour-corrected) value is a map of the byte: one weighted table per channel in LDS
+    __shared__ uint32_t wq[3][256];
     const int b = blockIdx.y;
     const int k = kind ? kind[b] : 0;
     const uint8_t *img = in + (size_t)b * npx * 3;
     uint8_t *g = gray + (size_t)b * npx;
     const bool aligned = (npx & 3) == 0;
-    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
+    for (int i = threadIdx.x; i < 768; i += 256) {
+        const int c = i >> 8;
+        const uint32_t q = quant_u8(px_val(i & 255, px_atten(k, c)));
+        const uint32_t w15[3] = {9798u, 19235u, 3735u}, w14[3] = {4899u, 9617u, 1868u};  // gray_fixed's coefficients
+        wq[c][i & 255] = q * (shift == 15 ? w15[c] : w14[c]);
+    }
+    __syncthreads();
+    const uint32_t half = shift == 15 ? 16384u : 8192u, sh = shift == 15 ? 15 : 14;
     for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {
         const int n = min(4, npx - p);
         const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
         uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            o[i] = gray_fixed(quant_u8(px_val(v.r[i], false)), quant_u8(px_val(v.g[i], ag)), quant_u8(px_val(v.b[i], ab)),
-                              shift);
+        for (int i = 0; i < 4; ++i) o[i] = (wq[0][v.r[i]] + wq[1][v.g[i]] + wq[2][v.b[i]] + half) >> sh;
         if (aligned && n == 4) {
             *reinterpret_cast<uint32_t *>(g + p) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
         } else {

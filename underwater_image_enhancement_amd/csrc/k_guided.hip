@@ -185,12 +185,18 @@ __global__ void __launch_bounds__(256) k_trans_init(const uint8_t *__restrict__ 
                                                     const float *__restrict__ A, int npx, float omega, float norm_eps,
                                                     int pre_clip, float *__restrict__ t0)
 {
+    // img / (A + eps) takes 256 values per channel: the IEEE divisions are done once per block into an LDS table
+    // (three per thread) instead of three per pixel, which made this kernel instruction-bound.
+    __shared__ float nrm[3][256];
     const int b = blockIdx.y;
     const int k = kind ? kind[b] : 0;
-    const float d0 = A[b * 3 + 0] + norm_eps, d1 = A[b * 3 + 1] + norm_eps, d2 = A[b * 3 + 2] + norm_eps;
     const uint8_t *img = in + (size_t)b * npx * 3;
     const bool aligned = (npx & 3) == 0;
-    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
+    for (int i = threadIdx.x; i < 768; i += 256) {
+        const int c = i >> 8;
+        nrm[c][i & 255] = px_val(i & 255, px_atten(k, c)) / (A[b * 3 + c] + norm_eps);
+    }
+    __syncthreads();
     float *trow = t0 + (size_t)b * npx;
     for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {
         const int n = min(4, npx - p);
@@ -198,10 +204,7 @@ __global__ void __launch_bounds__(256) k_trans_init(const uint8_t *__restrict__ 
         float o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float n0 = px_val(v.r[i], false) / d0;
-            const float n1 = px_val(v.g[i], ag) / d1;
-            const float n2 = px_val(v.b[i], ab) / d2;
-            const float dark = fminf(fminf(n0, n1), n2);
+            const float dark = fminf(fminf(nrm[0][v.r[i]], nrm[1][v.g[i]]), nrm[2][v.b[i]]);
             float t = 1.0f - omega * dark;
             if (pre_clip) t = fminf(fmaxf(t, 0.1f), 1.0f);
             o[i] = t;
