@@ -215,10 +215,16 @@ __device__ __forceinline__ int ab_to_xz(int i)
     return i <= 3390 ? i * 108 / 841 - (1 << 14) * 16 / 116 * 108 / 841 : i * i / (1 << 14) * i / (1 << 14);
 }
 
-// grid-stride over pixels, grid (n, B), block 256
+// One block per (interpolation cell, row chunk) and image.  Between the centres of four neighbouring tiles the four
+// tile LUTs a pixel blends are fixed, so the block copies them (a 4x4 window of tiles around the cell, which also
+// covers a boundary pixel that float rounding puts into the next cell) into LDS once; the four per-pixel LUT gathers
+// then hit LDS instead of global memory, where they made the kernel address-unit bound.
+// grid ((tx+1)*(ty+1)*nchunk, B), block 256
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
 __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
-                                                         const uint8_t *__restrict__ lut, ClaheGeom g, int gamma_mode,
-                                                         float gexp, uint8_t *__restrict__ out_u8,
+                                                         const uint8_t *__restrict__ lut, ClaheGeom g, int nchunk,
+                                                         int gamma_mode, float gexp, uint8_t *__restrict__ out_u8,
                                                          float *__restrict__ out_f32)
 {
     __shared__ int s_ltoyf[512];
@@ -226,7 +232,17 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     __shared__ int s_inv[9];
     __shared__ float s_ff[256];
     __shared__ uint8_t s_fu[256];
+    __shared__ __attribute__((aligned(4))) uint8_t s_lut[16][256];
     const int tid = threadIdx.x, b = blockIdx.y;
+    const int cell = blockIdx.x / nchunk, chunk = blockIdx.x - cell * nchunk;
+    const int cyi = cell / (g.tx + 1), cxi = cell - cyi * (g.tx + 1);
+    // nominal pixel rectangle of the cell: tile centres are at (i + 1/2) * tile size
+    const int cx0 = max(cxi * g.tw - g.tw / 2, 0), cx1 = min((cxi + 1) * g.tw - g.tw / 2, g.W);
+    const int ry0 = max(cyi * g.th - g.th / 2, 0), ry1 = min((cyi + 1) * g.th - g.th / 2, g.H);
+    const int rows_per = (ry1 - ry0 + nchunk - 1) / nchunk;
+    const int cy0 = ry0 + chunk * rows_per, cy1 = min(cy0 + rows_per, ry1);
+    if (cx0 >= cx1 || cy0 >= cy1) return;
+    const int wx0 = min(max(cxi - 2, 0), max(g.tx - 4, 0)), wy0 = min(max(cyi - 2, 0), max(g.ty - 4, 0));
     for (int i = tid; i < 512; i += 256) s_ltoyf[i] = T->ltoyf[i];
     for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
     if (tid < 9) s_inv[tid] = T->inv[tid];
@@ -235,35 +251,54 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         s_ff[tid] = y;
         s_fu[tid] = (uint8_t)quant_u8(y);
     }
-    __syncthreads();
-    const int npx = g.H * g.W;
-    const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
     const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int w = i >> 6, wy = w >> 2, wx = w & 3;
+        const int tyy = min(wy0 + wy, g.ty - 1), txx = min(wx0 + wx, g.tx - 1);
+        reinterpret_cast<uint32_t *>(&s_lut[w][0])[i & 63] =
+            reinterpret_cast<const uint32_t *>(Lt + (size_t)(tyy * g.tx + txx) * 256)[i & 63];
+    }
+    __syncthreads();
+    const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
     constexpr int BASE = 1 << 14;
-    const bool aligned = (npx & 3) == 0;
-    for (int p0 = (blockIdx.x * 256 + tid) * 4; p0 < npx; p0 += gridDim.x * 1024) {
-        const int n = min(4, npx - p0);
-        const Px4 in4 = load_px4(lab + ((size_t)b * npx + p0) * 3, n, aligned);  // r,g,b fields hold L,a,b
+    const int gpr = (cx1 - cx0 + 3) / 4, total = (cy1 - cy0) * gpr;  // 4-pixel groups per row, in the block
+    const uint32_t gmagic = (uint32_t)(((1ull << 32) + gpr - 1) / gpr);
+    for (int gi = tid; gi < total; gi += 256) {
+        const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr (gi < 2^32 / gpr)
+        const int y = cy0 + row, x0 = cx0 + 4 * xg, n = min(4, cx1 - x0);
+        const size_t pix = ((size_t)b * g.H + y) * g.W + x0;
+        Px4 in4;  // r,g,b fields hold L,a,b
+        if (n == 4) {
+            const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(lab + pix * 3);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            in4.r[0] = w0 & 255; in4.g[0] = (w0 >> 8) & 255; in4.b[0] = (w0 >> 16) & 255;
+            in4.r[1] = w0 >> 24; in4.g[1] = w1 & 255; in4.b[1] = (w1 >> 8) & 255;
+            in4.r[2] = (w1 >> 16) & 255; in4.g[2] = w1 >> 24; in4.b[2] = w2 & 255;
+            in4.r[3] = (w2 >> 8) & 255; in4.g[3] = (w2 >> 16) & 255; in4.b[3] = w2 >> 24;
+        } else {
+            in4 = load_px4(lab + pix * 3, n, false);
+        }
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, g.ty - 1);
+        const int r1 = min(max(ty1 - wy0, 0), 3) * 4, r2 = min(max(ty2 - wy0, 0), 3) * 4;
         uint32_t o0[4], o1[4], o2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = min(p0 + i, npx - 1);
-            const int y = p / g.W, x = p % g.W;
-            const float tyf = (float)y * inv_th - 0.5f;
-            int ty1 = (int)floorf(tyf);
-            int ty2 = ty1 + 1;
-            const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
-            ty1 = max(ty1, 0);
-            ty2 = min(ty2, g.ty - 1);
+            const int x = min(x0 + i, g.W - 1);
             const float txf = (float)x * inv_tw - 0.5f;
             int tx1 = (int)floorf(txf);
             int tx2 = tx1 + 1;
             const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
             tx1 = max(tx1, 0);
             tx2 = min(tx2, g.tx - 1);
+            const int c1 = min(max(tx1 - wx0, 0), 3), c2 = min(max(tx2 - wx0, 0), 3);
             const int v = in4.r[i], aa = in4.g[i], bb = in4.b[i];
-            const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
-            const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
+            const float l11 = (float)s_lut[r1 + c1][v], l12 = (float)s_lut[r1 + c2][v];
+            const float l21 = (float)s_lut[r2 + c1][v], l22 = (float)s_lut[r2 + c2][v];
             const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
             const int LL = sat_u8(__float2int_rn(res));
             // LAB2RGB (Lab2RGBinteger)
@@ -278,7 +313,7 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
             o1[i] = s_invgamma[go];
             o2[i] = s_invgamma[bo];
         }
-        const size_t o = ((size_t)b * npx + p0) * 3;
+        const size_t o = pix * 3;
         if (out_f32)
             for (int i = 0; i < n; ++i) {
                 out_f32[o + 3 * i] = s_ff[o0[i]];
@@ -292,7 +327,14 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
                 o1[i] = s_fu[o1[i]];
                 o2[i] = s_fu[o2[i]];
             }
-            store_px4(out_u8 + o, o0, o1, o2, n, aligned);
+            if (n == 4) {
+                u32_unaligned *w = reinterpret_cast<u32_unaligned *>(out_u8 + o);
+                w[0] = o0[0] | (o1[0] << 8) | (o2[0] << 16) | (o0[1] << 24);
+                w[1] = o1[1] | (o2[1] << 8) | (o0[2] << 16) | (o1[2] << 24);
+                w[2] = o2[2] | (o0[3] << 8) | (o1[3] << 16) | (o2[3] << 24);
+            } else {
+                store_px4(out_u8 + o, o0, o1, o2, n, false);
+            }
         }
     }
 }
@@ -456,8 +498,12 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     UWIE_LAUNCH(k_stretch_lab_lut, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, d_pct, pct_stride, eps, two,
                 g, lab, lut);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_clahe_apply_out, dim3(grid_for((s.npx() + 3) / 4, 2048), s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g,
-                gamma_mode, gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
+    // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
+    const int cells = (tx + 1) * (ty + 1);
+    int nchunk = cdiv(8192, cells * s.B);
+    nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
+    UWIE_LAUNCH(k_clahe_apply_out, dim3(cells * nchunk, s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g, nchunk, gamma_mode,
+                gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
