@@ -49,7 +49,8 @@ struct WaveCfg {
     static constexpr int region_doubles = 4 * SW;         // 2 planes x {P, slot-0 value}
     // two staging regions (alternating) unless that costs a resident wavefront per CU
     // staging regions: 1 measured faster than 2 alternating ones (6.6 vs 7.4 ms at 4K x 64, k = 15): LDS bytes per
-    // wavefront decide how many strips a CU holds, and that matters more than overlapping two staging round trips
+    // wavefront decide how many strips a CU holds (five up to 31.5 KB each, four beyond: measured), and that matters
+    // more than overlapping two staging round trips
     static constexpr int NREG = NREG_;
     static constexpr int lds_bytes = ring_bytes + NREG * region_doubles * 8;
 };
@@ -112,6 +113,17 @@ __device__ __forceinline__ double u8_over_255(uint32_t g)
     const double x = (double)g, rcp = 1.0 / 255.0;
     const double q0 = x * rcp;
     return fma(fma(-q0, 255.0, x), rcp, q0);
+}
+
+// 1/x by the hardware seed and two Newton steps: within ~2 ulp, which the kernel's 1e-11 tolerance on t covers with
+// four orders of magnitude to spare; the IEEE division sequence is more than twice as long and sits on the tick's
+// critical path (var + eps >= eps > 0, no special cases).
+__device__ __forceinline__ double recip_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
 }
 
 __device__ __forceinline__ int reflect_clamp(int p, int len)
@@ -274,7 +286,7 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
             for (int c = 0; c < 2; ++c) {
                 const double mI = m[0][c], mp = m[1][c], mIp = m[2][c], mII = m[3][c];
                 const double cov = mIp - mI * mp, var = mII - mI * mI;
-                av[c] = cov / (var + eps);
+                av[c] = cov * recip_nr(var + eps);
                 bv[c] = mp - av[c] * mI;
             }
             if (EDGE) {
