@@ -15,6 +15,9 @@ namespace uwie {
 
 namespace {
 
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint4 __attribute__((aligned(1))) u128_unaligned;
+
 __device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
 #define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
@@ -158,22 +161,76 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     const int area = g.tw * g.th;
     constexpr int Lscale = (116 * 255 + 50) / 100;
     constexpr int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
-    for (int i = tid; i < area; i += 256) {
-        const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
-        const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
-        const int R = s_gamma[quant_u8(S.apply(r0[p], 0))];
-        const int G = s_gamma[quant_u8(S.apply(r1[p], 1))];
-        const int B = s_gamma[quant_u8(S.apply(r2[p], 2))];
+    auto to_lab = [&](float v0, float v1, float v2, uint32_t &L, uint32_t &a, uint32_t &bb) {
+        const int R = s_gamma[quant_u8(S.apply(v0, 0))];
+        const int G = s_gamma[quant_u8(S.apply(v1, 1))];
+        const int B = s_gamma[quant_u8(S.apply(v2, 2))];
         const int fX = s_cbrt[UWIE_DESCALE(R * s_fwd[0] + G * s_fwd[1] + B * s_fwd[2], 12)];
         const int fY = s_cbrt[UWIE_DESCALE(R * s_fwd[3] + G * s_fwd[4] + B * s_fwd[5], 12)];
         const int fZ = s_cbrt[UWIE_DESCALE(R * s_fwd[6] + G * s_fwd[7] + B * s_fwd[8], 12)];
-        const uint8_t L = sat_u8(UWIE_DESCALE(Lscale * fY + Lshift, 15));
-        atomicAdd(&h[w][L], 1u);
-        if (ey < g.H && ex < g.W) {
-            uint8_t *o = labimg + (size_t)p * 3;
-            o[0] = L;
-            o[1] = sat_u8(UWIE_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
-            o[2] = sat_u8(UWIE_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
+        L = sat_u8(UWIE_DESCALE(Lscale * fY + Lshift, 15));
+        a = sat_u8(UWIE_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
+        bb = sat_u8(UWIE_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
+    };
+    // the tile's pixels inside the image: four per thread, 16-byte loads per plane, 12-byte LAB store
+    const int x_lo = txi * g.tw, x_hi = min(x_lo + g.tw, g.W), y_lo = ty * g.th, y_hi = min(y_lo + g.th, g.H);
+    const int gpr = max((x_hi - x_lo + 3) / 4, 0), total = max(y_hi - y_lo, 0) * gpr;
+    const uint32_t gmagic = (uint32_t)(((1ull << 32) + max(gpr, 1) - 1) / max(gpr, 1));
+    for (int gi = tid; gi < total; gi += 256) {
+        const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr
+        const int x0 = x_lo + 4 * xg, n = min(4, x_hi - x0), p = (y_lo + row) * g.W + x0;
+        float v0[4], v1[4], v2[4];
+        if (n == 4) {
+            *reinterpret_cast<uint4 *>(v0) = *reinterpret_cast<const u128_unaligned *>(r0 + p);
+            *reinterpret_cast<uint4 *>(v1) = *reinterpret_cast<const u128_unaligned *>(r1 + p);
+            *reinterpret_cast<uint4 *>(v2) = *reinterpret_cast<const u128_unaligned *>(r2 + p);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v0[i] = i < n ? r0[p + i] : 0.f;
+                v1[i] = i < n ? r1[p + i] : 0.f;
+                v2[i] = i < n ? r2[p + i] : 0.f;
+            }
+        }
+        uint32_t L[4], a[4], bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) to_lab(v0[i], v1[i], v2[i], L[i], a[i], bb[i]);
+        uint32_t cl = L[0], cn = 1;  // runs of equal L inside the group: one LDS atomic per run
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            if (i >= n) break;
+            if (L[i] == cl) {
+                ++cn;
+            } else {
+                atomicAdd(&h[w][cl], cn);
+                cl = L[i];
+                cn = 1;
+            }
+        }
+        atomicAdd(&h[w][cl], cn);
+        uint8_t *o = labimg + (size_t)p * 3;
+        if (n == 4) {
+            u32_unaligned *wd = reinterpret_cast<u32_unaligned *>(o);
+            wd[0] = L[0] | (a[0] << 8) | (bb[0] << 16) | (L[1] << 24);
+            wd[1] = a[1] | (bb[1] << 8) | (L[2] << 16) | (a[2] << 24);
+            wd[2] = bb[2] | (L[3] << 8) | (a[3] << 16) | (bb[3] << 24);
+        } else {
+            for (int i = 0; i < n; ++i) {
+                o[3 * i] = (uint8_t)L[i];
+                o[3 * i + 1] = (uint8_t)a[i];
+                o[3 * i + 2] = (uint8_t)bb[i];
+            }
+        }
+    }
+    // the part of the tile that hangs over the image edge (CLAHE pads by reflection): histogram only
+    if (x_lo + g.tw > g.W || y_lo + g.th > g.H) {
+        for (int i = tid; i < area; i += 256) {
+            const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
+            if (ey < g.H && ex < g.W) continue;
+            const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
+            uint32_t L, a, bb;
+            to_lab(r0[p], r1[p], r2[p], L, a, bb);
+            atomicAdd(&h[w][L], 1u);
         }
     }
     __syncthreads();
@@ -220,8 +277,6 @@ __device__ __forceinline__ int ab_to_xz(int i)
 // covers a boundary pixel that float rounding puts into the next cell) into LDS once; the four per-pixel LUT gathers
 // then hit LDS instead of global memory, where they made the kernel address-unit bound.
 // grid ((tx+1)*(ty+1)*nchunk, B), block 256
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-
 __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
                                                          const uint8_t *__restrict__ lut, ClaheGeom g, int nchunk,
                                                          int gamma_mode, float gexp, uint8_t *__restrict__ out_u8,
