@@ -16,6 +16,7 @@ and the MAX of the elapsed time.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -64,24 +65,50 @@ def synth_underwater(batch, H, W, device, seed):
     return out
 
 
-def cpu_baseline(H, W, seed, budget_s=25.0):
-    """Time the CPU oracle on a bounded sample: whole frames of the same workload, at least one, until ~budget."""
-    import numpy as np
+def synth_frames(dist, batch, H, W, device, seed):
+    """underwater (headline), or the reference's own self-test inputs: uniform bytes (enhancement_strategies.py:516) and
+    the hazy range floor(255 * (rand * 0.7 + 0.15)) (example_usage.py:112)."""
     import torch
+
+    if dist == "underwater":
+        return synth_underwater(batch, H, W, device, seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.rand((batch, H, W, 3), generator=g, device=device)
+    if dist == "hazy":
+        u = u * 0.7 + 0.15
+        return torch.floor(u * 255.0).to(torch.uint8)
+    return torch.clamp(torch.floor(u * 256.0), 0, 255).to(torch.uint8)
+
+
+def cpu_baseline(frames_host, gpu_out_host, strategy, budget_s=25.0):
+    """Time the CPU oracle on a bounded sample -- the first frames of the timed batch, at least one, until ~budget --
+    and compare the GPU output of those frames with it (max |delta| in LSB, uint8 PSNR)."""
+    import numpy as np
 
     from oracle import uwie_oracle as orc
 
-    frames = synth_underwater(8, H, W, torch.device("cpu"), seed).numpy()
-    orc.enhance_u8(np.ascontiguousarray(frames[0, : H // 8, : W // 8]), 2)  # warm-up (library load, tables)
-    done, t0 = 0, time.perf_counter()
-    while done < len(frames):
-        orc.enhance_u8(frames[done], 2)
+    H, W = frames_host.shape[1:3]
+    orc.enhance_u8(np.ascontiguousarray(frames_host[0, : H // 8, : W // 8]), strategy)  # warm-up (library load, tables)
+    done, t0, worst, sq, nbytes = 0, time.perf_counter(), 0, 0.0, 0
+    dt = 0.0
+    while done < len(frames_host):
+        t1 = time.perf_counter()
+        want = orc.enhance_u8(frames_host[done], strategy)
+        dt += time.perf_counter() - t1
+        d = np.abs(want.astype(np.int16) - gpu_out_host[done].astype(np.int16))
+        worst = max(worst, int(d.max()))
+        sq += float((d.astype(np.float64) ** 2).sum())
+        nbytes += d.size
         done += 1
         if time.perf_counter() - t0 > budget_s * 0.6:
             break
-    dt = time.perf_counter() - t0
+    mse = sq / nbytes
     return {"value": round(done * H * W / 1e6 / dt, 3), "unit": "megapixels/sec", "cores": 1, "kind": "port",
-            "sample": f"{done} frame(s) of {W}x{H} through oracle.enhance_u8 (NumPy + C restatement, 1 thread), {dt:.1f} s"}
+            "sample": f"{done} frame(s) of {W}x{H} (the first frames of the timed batch) through oracle.enhance_u8 "
+                      f"(NumPy + C restatement, 1 thread), {dt:.1f} s",
+            "gpu_vs_oracle_max_lsb": worst, "gpu_vs_oracle_psnr_db": None if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 2),
+            "gpu_vs_oracle_bytes_compared": nbytes}
 
 
 def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
@@ -97,6 +124,48 @@ def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
     return table[key]["hbm_bytes_per_px_per_step"] * B * H * W / max(launches_per_step, 1)
 
 
+def timed_enhance(dev, _lib, torch, frames, strategy, steps):
+    """ms per call of uwie_enhance_u8 on `frames` (one warm-up, then `steps` calls between two synchronisations)."""
+    import ctypes
+
+    B, H, W = frames.shape[:3]
+    p = dev.params(_lib.SURFACE_SIX, strategy)
+    ws = dev.workspace_for(B, H, W, p)
+    out = dev.empty((B, H, W, 3), torch.uint8)
+
+    def call():
+        _lib.check(dev.lib.uwie_enhance_u8(dev._ctx, ctypes.c_void_p(frames.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                           None, B, H, W, ctypes.byref(p), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                           dev.stream()))
+
+    call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def extras(dev, args, torch, _lib):
+    """Numbers SURVEY.md section 8d asks to see beside the headline: the other two input distributions on the same
+    workload (uniform noise is the worst case for the Canny / quadtree stages) and BASELINE.json configs[1]."""
+    H, W, B = args.height, args.width, args.batch
+    res = {}
+    for dist in ("uniform", "hazy"):
+        if dist == args.dist:
+            continue
+        fr = synth_frames(dist, B, H, W, dev.torch_device, seed=1000 * 2)
+        ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 2)
+        res[f"{dist}_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
+        del fr
+    one = synth_frames("underwater", 1, 1080, 1920, dev.torch_device, seed=1000 * 1)
+    ms = timed_enhance(dev, _lib, torch, one, args.strategy, 10)
+    res["configs1_1080p_batch1_ms"] = round(ms, 3)
+    res["configs1_1080p_batch1_megapixels_per_sec"] = round(1080 * 1920 / 1e3 / ms, 1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +175,10 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--strategy", type=int, default=2)
+    ap.add_argument("--dist", choices=("underwater", "uniform", "hazy"), default="underwater",
+                    help="synthetic input distribution (SURVEY.md section 8d); the headline number uses underwater")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other input distributions and the 1080p batch=1 case")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +198,7 @@ def main():
 
     dev = uw.get_device(local)
     H, W, B = args.height, args.width, args.batch
-    frames = synth_underwater(B, H, W, dev.torch_device, seed=1000 * 2 + rank)
+    frames = synth_frames(args.dist, B, H, W, dev.torch_device, seed=1000 * 2 + rank)
     p = dev.params(_lib.SURFACE_SIX, args.strategy)
     ws = dev.workspace_for(B, H, W, p)
     out = dev.empty((B, H, W, 3), torch.uint8)
@@ -174,8 +246,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64",
             "data": "synthetic",
-            "config": {"workload": f"{W}x{H} RGB u8, batch={B} per GPU, strategy{args.strategy} + cast correction "
-                                   "(canonical enhance, BASELINE.json configs[2])",
+            "config": {"workload": f"{W}x{H} RGB u8 ({args.dist}), batch={B} per GPU, strategy{args.strategy} + cast "
+                                   "correction (canonical enhance, BASELINE.json configs[2])",
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -188,7 +260,10 @@ def main():
                          "sum_kernel_ms_per_step": round(kernel_ms, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(H, W, seed=2000)
+            n_cmp = min(B, 8)
+            result["cpu_baseline"] = cpu_baseline(frames[:n_cmp].cpu().numpy(), out[:n_cmp].cpu().numpy(), args.strategy)
+        if world == 1 and not args.no_extras:
+            result["extras"] = extras(dev, args, torch, _lib)
         if os.environ.get("UWIE_BENCH_KERNELS"):
             top = sorted(rows.items(), key=lambda kv: -kv[1][0])
             print("# per-kernel ms/step: " + ", ".join(f"{k}={v[0] / args.steps:.3f}({v[1] // args.steps})" for k, v in top),
