@@ -120,6 +120,8 @@ def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
     table = json.load(open(path))["kernels"]
     key = kernel.replace("<TH>", "<8>").replace("<V>", "<float>")
     if key not in table:
+        key = key.split("<")[0]
+    if key not in table:
         return None
     return table[key]["hbm_bytes_per_px_per_step"] * B * H * W / max(launches_per_step, 1)
 

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT.$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > $OUT.$name.log 2>&1
 }
 BENCH_ARGS=("$@")
 mkdir -p $OUT
