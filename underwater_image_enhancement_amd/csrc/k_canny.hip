@@ -55,10 +55,41 @@ __device__ __forceinline__ v2s byte_pair(uint32_t lo, uint32_t hi)
     return as_v2s(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)I | ((uint32_t)J << 16)));
 }
 
+// lock-free union-find on tile-local indices in LDS (links point to the smaller index)
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *L, int i)
+{
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ int lds_find(uint32_t *L, int i)
+{
+    for (;;) {
+        const int p = (int)lds_ld(L, i);
+        if (p == i) return i;
+        const int gp = (int)lds_ld(L, p);
+        if (gp == p) return p;
+        atomicMin(L + i, (uint32_t)gp);
+        i = gp;
+    }
+}
+__device__ void lds_union(uint32_t *L, int a, int b)
+{
+    for (;;) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const uint32_t old = atomicCAS(L + a, (uint32_t)a, (uint32_t)b);
+        if ((int)old == a) return;
+        a = (int)old;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
                                                        int H, int W, int tiles_x, int low, int high, CannyBufs bufs)
 {
     __shared__ __attribute__((aligned(8))) uint8_t sg[kSG_H][kSG_W];
+    __shared__ uint32_t s_lab[kCT_H * kCT_W];
+    __shared__ uint8_t s_keep[256];
     const Region r = regs[blockIdx.y];
     const int ty0 = (blockIdx.x / tiles_x) * kCT_H, tx0 = (blockIdx.x % tiles_x) * kCT_W;  // tile origin inside the region
     const int tid = threadIdx.x;
@@ -165,15 +196,39 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
         else
             for (int j = 0; j < r.cols - rx0; ++j) dst[j] = (uint8_t)(cls[i] >> (8 * j));
     }
-    // candidate list of this (tile, wavefront): fixed slot, so no atomics and nothing to wait for
+    // ---- tile-local components in LDS: on dense maps (noise inputs) nearly every pixel is a candidate and a union-find
+    // over global memory alone is contention-bound; merging inside the tile first leaves only the tile-border links to it
+    s_keep[tid] = (uint8_t)keepmask;  // 4x2 candidate bits of this thread's block
+    for (uint32_t km = keepmask; km; km &= km - 1) {
+        const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
+        s_lab[li] = li;
+    }
+    __syncthreads();
+    auto is_cand = [&](int ly, int lx) -> bool {  // tile coordinates, inside the tile
+        return (s_keep[(ly >> 1) * 16 + (lx >> 2)] >> (((ly & 1) << 2) | (lx & 3))) & 1;
+    };
+    for (uint32_t km = keepmask; km; km &= km - 1) {
+        const int b = __ffs(km) - 1, ly = 2 * rp + (b >> 2), lx = 4 * cg + (b & 3), li = ly * kCT_W + lx;
+        if (lx + 1 < kCT_W && is_cand(ly, lx + 1)) lds_union(s_lab, li, li + 1);
+        if (ly + 1 < kCT_H) {
+            if (lx > 0 && is_cand(ly + 1, lx - 1)) lds_union(s_lab, li, li + kCT_W - 1);
+            if (is_cand(ly + 1, lx)) lds_union(s_lab, li, li + kCT_W);
+            if (lx + 1 < kCT_W && is_cand(ly + 1, lx + 1)) lds_union(s_lab, li, li + kCT_W + 1);
+        }
+    }
+    __syncthreads();
+    // candidate list of this (tile, wavefront): fixed slot, so no atomics and nothing to wait for; every candidate's
+    // global label starts at the root of its tile-local component
     const uint32_t incl = wave_incl_scan_u32(ncand);
     if ((tid & 63) == 63) bufs.ncand[sub] = incl;
     if (ncand) {
         uint32_t *dst = bufs.cand + sub * 512 + (incl - ncand);
         for (uint32_t km = keepmask; km; km &= km - 1) {
-            const int b = __ffs(km) - 1;
+            const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
+            const int root = lds_find(s_lab, li);
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
-            bufs.label[base + p] = p;
+            const int proot = (r.y0 + ty0 + root / kCT_W) * W + r.x0 + tx0 + root % kCT_W;
+            bufs.label[base + p] = proot;
             bufs.flag[base + p] = 0;
             *dst++ = (uint32_t)p;
         }
@@ -246,13 +301,16 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
     const uint8_t *cm = bufs.cmap + base;
     int32_t *L = bufs.label + base;
     for_candidates(bufs, [&](int p) {
+        // links inside a tile were made in LDS by k_canny_gradnms: only pairs that straddle a tile border are left
         const int y = p / W, x = p - y * W;
+        const int lx = (x - r.x0) % kCT_W, ly = (y - r.y0) % kCT_H;
         const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
-        if (right && cm[p + 1] != 1) uf_union(L, p, p + 1);
+        const bool xr = lx == kCT_W - 1, xl = lx == 0, yd = ly == kCT_H - 1;
+        if (right && xr && cm[p + 1] != 1) uf_union(L, p, p + 1);
         if (down) {
-            if (left && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
-            if (cm[p + W] != 1) uf_union(L, p, p + W);
-            if (right && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
+            if (left && (yd || xl) && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
+            if (yd && cm[p + W] != 1) uf_union(L, p, p + W);
+            if (right && (yd || xr) && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
         }
     });
 }
