@@ -161,6 +161,15 @@ def extras(dev, args, torch, _lib):
         ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 2)
         res[f"{dist}_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
         del fr
+    # N1: the batch driver's fan-out, all six strategies per frame with shared cast detection / quadtree
+    fan = synth_frames("underwater", min(B, 16), H, W, dev.torch_device, seed=1000 * 2)
+    dev.enhance_all_u8(fan)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.enhance_all_u8(fan)
+    torch.cuda.synchronize()
+    res["all_six_strategies_input_megapixels_per_sec"] = round(fan.shape[0] * H * W / 1e6 / (time.perf_counter() - t0), 1)
+    del fan
     one = synth_frames("underwater", 1, 1080, 1920, dev.torch_device, seed=1000 * 1)
     ms = timed_enhance(dev, _lib, torch, one, args.strategy, 10)
     res["configs1_1080p_batch1_ms"] = round(ms, 3)

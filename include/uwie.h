@@ -110,6 +110,17 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p);
 int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float *d_out_f32, int batch, int H, int W,
                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The batch driver's inner loop (six_stadigy.py:398-431): one cast detection / correction per image, then all six
+ * strategies on the corrected image.  The gray plane and the atmospheric light depend on the corrected image only, so
+ * strategies 1-3 share one quadtree instead of running three (the reference recomputes it, with the same result).
+ * d_out_u8 is [6][batch][H][W][3]: plane k holds strategy k+1.  d_kind (optional) receives UWIE_CAST_* per image
+ * (the driver's image_type column).  p6: six parameter sets, strategies 1..6 in order, or NULL for the reference defaults.
+ * Workspace: uwie_workspace_bytes(batch, H, W, <a strategy 1-3 parameter set>).
+ */
+int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, int32_t *d_kind, int batch, int H, int W,
+                        const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------- per-stage entry points (parity tests, composition) ---------------- */
 
 /* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */

@@ -123,3 +123,23 @@ def test_u8_over_255_identity_f32():
         r = rn(F(float(x)) - F(float(q0)) * 255)
         q = rn(F(float(r)) * F(float(rcp)) + F(float(q0)))
         assert q == f32(u) / f32(255.0), u
+
+
+def test_process_batch_log_rows_match_the_driver_columns():
+    """Host bookkeeping of the batch driver (six_stadigy.py:369-500) with an injected compute: no GPU needed."""
+    import numpy as np
+
+    frames = np.zeros((2, 4, 5, 3), np.uint8)
+
+    def fake(f):
+        return {n: f.copy() for n, _ in uw.DRIVER_STRATEGIES}, ["greenish", "normal"]
+
+    outs, rows, stats = uw.process_batch(frames, ["x.jpg", "y.jpg"], compute=fake)
+    assert [r["strategy"] for r in rows[:6]] == ["strong_dehazing", "medium_dehazing", "light_dehazing",
+                                                  "clahe_enhancement", "white_balance", "histogram_eq"]
+    assert set(rows[0]) == {"filename", "image_type", "strategy", "strategy_desc", "status", "processing_time"}
+    assert rows[0]["image_type"] == "greenish" and rows[6]["filename"] == "y.jpg" and rows[6]["image_type"] == "normal"
+    assert stats["image_types"] == {"greenish": 1, "bluish": 0, "normal": 1} and stats["successful_outputs"] == 12
+    assert stats["processed_images"] == 2 and stats["total_images"] == 2
+    with pytest.raises(ValueError):
+        uw.process_batch(frames, ["only-one"], compute=fake)

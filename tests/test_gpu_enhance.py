@@ -177,3 +177,32 @@ def test_config2_4k_frame_matches_oracle_and_batch_is_invariant(uw, orc):
         assert np.array_equal(out[b], uw.enhance(frames[b]))
     assert np.array_equal(uw.enhance(frames[::-1].copy())[::-1], out)
     assert np.array_equal(uw.enhance(frames[2], cast_correct=False), out[2])  # neutral noise is classified "normal"
+
+
+def test_enhance_all_equals_the_six_single_strategy_calls(uw, orc):
+    """uwie_enhance_all_u8 (N1: the batch driver's fan-out, six_stadigy.py:398-431) shares cast detection, gray plane
+    and quadtree across strategies; every plane must equal the single-strategy call bit for bit, the image types must
+    be detect_image_type's, and one frame is checked against the oracle directly."""
+    frames = frames_for_tests(np.random.default_rng(515))
+    frames.pop("tiny_5x7")
+    for name, u8 in frames.items():
+        outs, types = uw.enhance_all(u8)
+        assert list(outs) == [n for n, _ in uw.DRIVER_STRATEGIES]
+        assert types == [orc.classify_cast(orc.normalise_u8(u8))]
+        for k, sname in enumerate(outs, start=1):
+            assert np.array_equal(outs[sname], uw.enhance(u8, strategy=k)), (name, sname)
+    name, u8 = next(iter(frames.items()))
+    outs, _ = uw.enhance_all(u8)
+    for k, sname in enumerate(outs, start=1):
+        check_u8(outs[sname], orc.enhance_u8(u8, k), f"enhance_all {sname} on {name}")
+    rng = np.random.default_rng(9)
+    batch = rng.integers(0, 256, (3, 70, 90, 3), dtype=np.uint8)
+    batch[1, :, :, 0] //= 3  # a frame with a cast
+    outs, types = uw.enhance_all(batch)
+    for b in range(3):
+        one, t1 = uw.enhance_all(batch[b])
+        assert t1 == [types[b]]
+        for sname in outs:
+            assert np.array_equal(outs[sname][b], one[sname])
+    _, rows, stats = uw.process_batch(batch, ["a.png", "b.png", "c.png"])
+    assert len(rows) == 18 and stats["successful_outputs"] == 18 and sum(stats["image_types"].values()) == 3

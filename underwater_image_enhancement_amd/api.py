@@ -62,6 +62,59 @@ def enhance(frames, strategy: int = 2, cast_correct: bool = True, device: int | 
     return _finish(outf if return_float else out, was_numpy, single)
 
 
+# ------------------------------------------------------------------ the batch driver's fan-out (six_stadigy.py:330-520)
+# (name, description) of the driver's strategy table, six_stadigy.py:344-351
+DRIVER_STRATEGIES = (
+    ("strong_dehazing", "強力去霧"), ("medium_dehazing", "中度去霧"), ("light_dehazing", "輕度去霧"),
+    ("clahe_enhancement", "CLAHE增強"), ("white_balance", "白平衡主導"), ("histogram_eq", "直方圖均衡"),
+)
+CAST_NAMES = ("normal", "greenish", "bluish")
+
+
+def enhance_all(frames, cast_correct: bool = True, device: int | None = None):
+    """All six strategies of every frame in one call: one cast detection and one atmospheric-light quadtree per frame
+    (strategies 1-3 share it), like the inner loop of ``process_all_images_all_strategies`` (six_stadigy.py:398-431).
+
+    Returns ``(outputs, image_types)``: ``outputs[name]`` is the uint8 batch of that strategy (keys in the driver's
+    order, see ``DRIVER_STRATEGIES``), ``image_types`` the list of ``"normal" / "greenish" / "bluish"`` per frame.
+    """
+    dev = get_device(device)
+    batch, was_numpy, single = _as_batch_u8(frames, dev)
+    out, kind = dev.enhance_all_u8(batch, cast_correct)
+    types = [CAST_NAMES[int(k)] for k in kind.cpu().tolist()]
+    outs = {name: _finish(out[i], was_numpy, single) for i, (name, _) in enumerate(DRIVER_STRATEGIES)}
+    return outs, types
+
+
+def process_batch(frames, filenames=None, device: int | None = None, compute=None):
+    """Host mirror of the driver's bookkeeping (six_stadigy.py:369-500) for frames that are already decoded: returns
+    ``(outputs, log_rows, stats)`` where ``log_rows`` has one dict per (image, strategy) with the driver's columns
+    (``filename, image_type, strategy, strategy_desc, status, processing_time``) and ``stats`` its counters.  File
+    I/O (glob / imread / imwrite / CSV) stays with the caller.  ``compute`` (tests) replaces ``enhance_all``.
+    """
+    import time
+
+    n = len(frames)
+    filenames = list(filenames) if filenames is not None else [f"frame_{i:05d}" for i in range(n)]
+    if len(filenames) != n:
+        raise ValueError("one filename per frame")
+    stats = {"total_images": n, "processed_images": 0, "failed_images": 0, "total_outputs": 0, "successful_outputs": 0,
+             "failed_outputs": 0, "image_types": {"greenish": 0, "bluish": 0, "normal": 0}}
+    t0 = time.time()
+    outs, types = (compute or (lambda f: enhance_all(f, device=device)))(frames)
+    per_image = (time.time() - t0) / max(n, 1)
+    rows = []
+    for i, name in enumerate(filenames):
+        stats["image_types"][types[i]] += 1
+        for sname, sdesc in DRIVER_STRATEGIES:
+            rows.append({"filename": name, "image_type": types[i], "strategy": sname, "strategy_desc": sdesc,
+                         "status": "success", "processing_time": f"{per_image:.2f}s"})
+            stats["successful_outputs"] += 1
+            stats["total_outputs"] += 1
+        stats["processed_images"] += 1
+    return outs, rows, stats
+
+
 # ------------------------------------------------------------------ float <-> u8 bridging
 def _recover_u8(img):
     """Invert ``u8.astype(float32)/255`` [+ ``color_correction``] exactly; returns (u8 frame, cast kind)."""

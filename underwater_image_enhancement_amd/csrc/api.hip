@@ -116,38 +116,61 @@ int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipSt
     return launch_stretch_apply_f32(P.F, P.pct, 2, 0, 1, eps, P.F, s, st);
 }
 
+// Cast detection (or the forced kind): what every six_stadigy strategy starts from.
+int six_cast(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, const int32_t **kind,
+             hipStream_t st)
+{
+    *kind = nullptr;
+    if (p->forced_cast >= 0) {
+        UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
+        *kind = P.kind;
+    } else if (p->cast_correct) {
+        UWIE_TRY(launch_cast_classify(ctx, d_in, s, P.kind, nullptr, P.scratch, st));
+        *kind = P.kind;
+    }
+    return UWIE_OK;
+}
+
+// Gray plane and atmospheric light: they depend on the (colour-corrected) frame only, so strategies 1-3 share them.
+int six_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Shape s, const uwie_params *p, const Pipe &P,
+                 hipStream_t st)
+{
+    UWIE_TRY(launch_quant_gray(d_in, kind, P.gray, s, p->gray_shift, st));
+    return launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st);
+}
+
+// Strategies 1-3 from (kind, gray, A) on: transmission -> guided filter -> restore -> stretch -> CLAHE / white balance.
+int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Shape s, const uwie_params *p, const Pipe &P,
+                    uint8_t *d_out_u8, float *d_out_f32, hipStream_t st)
+{
+    const float eps = 1e-6f;  // six_stadigy.py:198,218
+    const int k = p->strategy;
+    UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
+    UWIE_TRY(stage_guided(P, s, p, st));
+    // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
+    SelectPlan plan;
+    const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
+    UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
+    UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
+    UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
+    if (k == 3) {
+        UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));
+        return launch_tail_plain(P.F, P.pct, 4, eps, 1, s, 0, 1.0, d_out_u8, d_out_f32, st);
+    }
+    UWIE_TRY(select_lerp(plan, s, P.pct, st));
+    return launch_tail_clahe(ctx, P.F, P.pct, 2, eps, 0, s, p->clip_limit, p->tiles_x, p->tiles_y, k == 1 ? 1 : 0,
+                             p->gamma, d_out_u8, d_out_f32, P.scratch, st);
+}
+
 // Writes the strategy's float image to d_out_f32 and/or its (y*255).astype(u8) image to d_out_u8.
 int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
             float *d_out_f32, hipStream_t st)
 {
     const int32_t *kind = nullptr;
-    if (p->forced_cast >= 0) {
-        UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
-        kind = P.kind;
-    } else if (p->cast_correct) {
-        UWIE_TRY(launch_cast_classify(ctx, d_in, s, P.kind, nullptr, P.scratch, st));
-        kind = P.kind;
-    }
-    const float eps = 1e-6f;  // six_stadigy.py:198,218
-    const int k = p->strategy;
-    if (k >= 1 && k <= 3) {
-        UWIE_TRY(launch_quant_gray(d_in, kind, P.gray, s, p->gray_shift, st));
-        UWIE_TRY(launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
-        UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
-        UWIE_TRY(stage_guided(P, s, p, st));
-        // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
-        SelectPlan plan;
-        const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
-        UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
-        UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
-        if (k == 3) {
-            UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));
-            return launch_tail_plain(P.F, P.pct, 4, eps, 1, s, 0, 1.0, d_out_u8, d_out_f32, st);
-        }
-        UWIE_TRY(select_lerp(plan, s, P.pct, st));
-        return launch_tail_clahe(ctx, P.F, P.pct, 2, eps, 0, s, p->clip_limit, p->tiles_x, p->tiles_y, k == 1 ? 1 : 0,
-                                 p->gamma, d_out_u8, d_out_f32, P.scratch, st);
+    UWIE_TRY(six_cast(ctx, d_in, s, p, P, &kind, st));
+    if (p->strategy >= 1 && p->strategy <= 3) {
+        UWIE_TRY(six_airlight(ctx, d_in, kind, s, p, P, st));
+        return six_dehaze_tail(ctx, d_in, kind, s, p, P, d_out_u8, d_out_f32, st);
     }
     // strategies 4-6 never leave 8-bit data for long: evaluated as per-image LUT chains (k_codes.hip)
     return launch_code_strategy(ctx, d_in, kind, s, p, d_out_u8, d_out_f32, P.scratch, st);
@@ -334,6 +357,42 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
     }
     if (!dehazes(p)) return launch_code_strategy(ctx, d_in, nullptr, s, p, d_out_u8, d_out_f32, P.scratch, st);
     return run_dict_dehaze(ctx, d_in, s, p, P, d_out_u8, d_out_f32, st);
+}
+
+int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, int32_t *d_kind, int batch, int H, int W,
+                        const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_out_u8, "enhance_all: NULL context or image pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    uwie_params P6[6];
+    for (int k = 0; k < 6; ++k) {
+        if (p6) P6[k] = p6[k];
+        else UWIE_TRY(uwie_params_init(&P6[k], UWIE_SURFACE_SIX, k + 1));
+        UWIE_TRY(check_params(&P6[k]));
+        UWIE_REQUIRE(P6[k].surface == UWIE_SURFACE_SIX && P6[k].strategy == k + 1, "enhance_all: params must be strategies 1..6 in order");
+        UWIE_REQUIRE(P6[k].cast_correct == P6[0].cast_correct && P6[k].forced_cast == P6[0].forced_cast &&
+                         P6[k].gray_shift == P6[0].gray_shift && P6[k].min_size == P6[0].min_size,
+                     "enhance_all: the six parameter sets must agree on the shared stages (cast, gray, quadtree)");
+    }
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    Pipe P = carve_pipe(c, s, &P6[0]);  // a dehazing strategy's layout covers the other five
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t *kind = nullptr;
+    UWIE_TRY(six_cast(ctx, d_in, s, &P6[0], P, &kind, st));
+    if (d_kind) {
+        if (kind) UWIE_HIP_CHECK(hipMemcpyAsync(d_kind, kind, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, st));
+        else UWIE_HIP_CHECK(hipMemsetAsync(d_kind, 0, sizeof(int32_t) * batch, st));
+    }
+    UWIE_TRY(six_airlight(ctx, d_in, kind, s, &P6[0], P, st));
+    const size_t out_stride = (size_t)batch * H * W * 3;
+    for (int k = 0; k < 6; ++k) {
+        uint8_t *out = d_out_u8 + (size_t)k * out_stride;
+        if (k < 3) UWIE_TRY(six_dehaze_tail(ctx, d_in, kind, s, &P6[k], P, out, nullptr, st));
+        else UWIE_TRY(launch_code_strategy(ctx, d_in, kind, s, &P6[k], out, nullptr, P.scratch, st));
+    }
+    return UWIE_OK;
 }
 
 /* ---------------------------------------------------------------- stage entry points */
