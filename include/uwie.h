@@ -121,6 +121,20 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
 int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, int32_t *d_kind, int batch, int H, int W,
                         const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * DifferentiableEnhancement.forward (vgg_16_UIE.py:32-128), the arithmetic behind
+ * EnhancementPredictor.enhance_image (use_trained_model.py:83-111): per channel stretch between the sorted
+ * positions int(L_low/100*n) and int(L_high/100*n) (torch.sort) -> [UWIE_DIFF_OMEGA] dark-channel dehazing with
+ * A = 0.6 -> [UWIE_DIFF_GAMMA] pow(x + 1e-8, gamma) -> clamp(0, 1).  float32 in, float32 out, same layout:
+ * planar != 0: [batch][3][H][W] (the module's NCHW), else [batch][H][W][3].
+ * d_params: [batch][4] float32 = {L_low, L_high, omega, gamma} (the module's (B,1) parameter tensors).
+ * Bit-exact against torch on the CPU except pow (<= 1 float32 ulp).  Workspace: uwie_workspace_bytes.
+ */
+#define UWIE_DIFF_OMEGA 1
+#define UWIE_DIFF_GAMMA 2
+int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, int planar,
+                          const float *d_params, int flags, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------- per-stage entry points (parity tests, composition) ---------------- */
 
 /* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */

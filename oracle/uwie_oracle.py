@@ -443,3 +443,44 @@ CONFIG_STRATEGIES = {
     "clahe_enhancement": dict(clip_limit=2.0, tile_grid_size=(8, 8), apply_gamma=False),
     "histogram_equalization": dict(L_low=10, L_high=95),
 }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# vgg_16_UIE.DifferentiableEnhancement / extract_all_features.
+# The reference evaluates these with PyTorch / NumPy on the CPU; the restatement uses the same libraries for the
+# arithmetic (torch.sort, float32 tensor ops, torch.pow) so that it is bit-identical to the reference on the machine
+# that runs both (tests/golden/vgg_stages.npz holds outputs of the real module, oracle/gen_golden_vgg.py).
+def diff_enhance(img_bchw, params):
+    """DifferentiableEnhancement.forward, vgg_16_UIE.py:32-55.  img: (B,3,H,W) float32; params: dict of (B,1) float32
+    arrays with L_low, L_high and optionally omega, gamma.  Returns a float32 ndarray."""
+    import torch
+
+    img = torch.as_tensor(np.ascontiguousarray(img_bchw, dtype=np.float32))
+    par = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)).reshape(-1, 1) for k, v in params.items()}
+    B, C, H, W = img.shape
+    out = torch.zeros_like(img)
+    for b in range(B):  # color_stretch_batch, vgg_16_UIE.py:57-93
+        for c in range(C):
+            ch = img[b, c]
+            srt, _ = torch.sort(ch.flatten())
+            n = len(srt)
+            lo_i = max(0, min(int((par["L_low"][b].item() / 100.0) * n), n - 1))
+            hi_i = max(0, min(int((par["L_high"][b].item() / 100.0) * n), n - 1))
+            rng = srt[hi_i] - srt[lo_i] + 1e-8
+            out[b, c] = torch.clamp((ch - srt[lo_i]) / rng, 0, 1)
+    if "omega" in par:  # dehaze_batch, vgg_16_UIE.py:95-117
+        omega = par["omega"].view(-1, 1, 1, 1)
+        dark = torch.min(out, dim=1, keepdim=True)[0]
+        t = torch.clamp(1 - omega * dark, 0.1, 1.0)
+        out = torch.clamp((out - 0.6) / t + 0.6, 0, 1)
+    if "gamma" in par:  # gamma_correction, vgg_16_UIE.py:119-128
+        out = torch.pow(out + 1e-8, par["gamma"].view(-1, 1, 1, 1))
+    return torch.clamp(out, 0, 1).numpy()
+
+
+def diff_enhance_image(img_hwc, params):
+    """EnhancementPredictor.enhance_image with explicit parameters, use_trained_model.py:83-111."""
+    x = np.asarray(img_hwc, dtype=np.float32)
+    par = {k: np.array([[float(params[k])]], np.float32) for k in ("omega", "gamma", "L_low", "L_high")}
+    out = diff_enhance(np.ascontiguousarray(x.transpose(2, 0, 1))[None], par)[0].transpose(1, 2, 0)
+    return np.clip(out, 0.0, 1.0)

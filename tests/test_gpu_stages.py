@@ -306,3 +306,43 @@ def test_atmospheric_light_matches_oracle_trace(dev, orc, frames):
             same(rec["score"], np.array(scores, np.float64))
         assert tr[0, len(trace)]["rows"] == 0
         same(A[0].cpu().numpy(), np.asarray(want_A))
+
+
+# ------------------------------------------------------------------ vgg_16_UIE.DifferentiableEnhancement (N3)
+def test_diff_enhance_matches_reference_outputs_and_oracle(dev, orc):
+    """uwie_diff_enhance_f32 against the real module's outputs (tests/golden/vgg_stages.npz) and the torch-CPU oracle:
+    bit-exact without gamma; with gamma <= 1 float32 ulp (the device rounds pow once from float64, torch's float32
+    pow is a 1-ulp routine) -- except where the clamp at 1.0 hides the difference."""
+    import os
+
+    import torch
+
+    import underwater_image_enhancement_amd as uw
+    from test_oracle_golden import ulp_distance_f32
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_stages.npz"))
+    tags = sorted({k.split("/")[0] for k in z.files})
+    enh = uw.DifferentiableEnhancement()
+    for tag in tags:
+        par = {k: z[f"{tag}/{k}"] for k in ("L_low", "L_high", "omega", "gamma") if f"{tag}/{k}" in z.files}
+        got = enh(z[f"{tag}/img"], par)
+        want = z[f"{tag}/out"]
+        assert got.dtype == np.float32 and got.shape == want.shape
+        if "gamma" in par:
+            assert ulp_distance_f32(got, want).max() <= 1, tag
+        else:
+            same(got, want)
+    # larger seeded cases against the oracle, both layouts, torch tensors in and out
+    rng = np.random.default_rng(31)
+    img = rng.random((2, 3, 211, 157), dtype=np.float32)
+    par = {"L_low": np.array([[7.5], [22.0]], np.float32), "L_high": np.array([[91.0], [70.0]], np.float32),
+           "omega": np.array([[0.35], [0.8]], np.float32), "gamma": np.array([[0.6], [2.4]], np.float32)}
+    want = orc.diff_enhance(img, par)
+    got = enh(dev.tensor(img), {k: torch.from_numpy(v) for k, v in par.items()})
+    assert isinstance(got, torch.Tensor) and got.is_cuda
+    assert ulp_distance_f32(got.cpu().numpy(), want).max() <= 1
+    nog = {k: v for k, v in par.items() if k != "gamma"}
+    same(enh(img, nog), orc.diff_enhance(img, nog))
+    hwc = np.ascontiguousarray(img[0].transpose(1, 2, 0))
+    p1 = {"L_low": 7.5, "L_high": 91.0, "omega": 0.35, "gamma": 0.6}
+    assert ulp_distance_f32(enh.enhance_image(hwc, p1), orc.diff_enhance_image(hwc, p1)).max() <= 1

@@ -60,3 +60,36 @@ def test_dict_strategy_numpy_stages(golden, tag):
     same(ES.stretch(x, 15, 95), golden[f"{tag}/es_stretch_f32_15_95"])
     same(ES.gamma(rec, 1.2), golden[f"{tag}/es_gamma_1.2"])
     same(orc.brightest_pixel(x), golden[f"{tag}/es_brightest"])
+
+
+# ------------------------------------------------------------------ vgg_16_UIE.DifferentiableEnhancement (N3)
+def _vgg_cases():
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_stages.npz"))
+    tags = sorted({k.split("/")[0] for k in z.files})
+    return z, tags
+
+
+def ulp_distance_f32(a, b):
+    ia = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+def test_diff_enhance_oracle_matches_the_reference_module():
+    """oracle.diff_enhance against outputs of the real vgg_16_UIE.DifferentiableEnhancement (oracle/gen_golden_vgg.py).
+    Stretch and dehazing are bit-exact; torch.pow on float32 may pick another CPU kernel on another machine: <= 1 ulp."""
+    from oracle import uwie_oracle as orc
+
+    z, tags = _vgg_cases()
+    assert len(tags) == 5
+    for tag in tags:
+        par = {k: z[f"{tag}/{k}"] for k in ("L_low", "L_high", "omega", "gamma") if f"{tag}/{k}" in z.files}
+        got = orc.diff_enhance(z[f"{tag}/img"], par)
+        want = z[f"{tag}/out"]
+        assert got.dtype == np.float32 and got.shape == want.shape
+        if "gamma" in par:
+            assert ulp_distance_f32(got, want).max() <= 1, tag
+        else:
+            assert np.array_equal(got, want), tag

@@ -115,6 +115,52 @@ def process_batch(frames, filenames=None, device: int | None = None, compute=Non
     return outs, rows, stats
 
 
+# ------------------------------------------------------------------ vgg_16_UIE.DifferentiableEnhancement (N3)
+class DifferentiableEnhancement:
+    """Forward pass of ``vgg_16_UIE.DifferentiableEnhancement`` (vgg_16_UIE.py:24-128) on the device.
+
+    ``forward(img, params)``: ``img`` is ``(B, 3, H, W)`` float32 (NumPy or torch ROCm tensor), ``params`` a dict of
+    ``(B, 1)``-shaped values with the reference's keys: ``L_low`` and ``L_high`` are required, ``omega`` and ``gamma``
+    optional (a missing key skips that stage, vgg_16_UIE.py:48,52).  Not differentiable: inference only.
+    """
+
+    device: int | None = None
+
+    def forward(self, img, params):
+        dev = get_device(self.device)
+        was_numpy = not hasattr(img, "data_ptr")
+        x = dev.tensor(np.ascontiguousarray(img, dtype=np.float32)) if was_numpy else img
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected a (B, 3, H, W) image batch, got {tuple(x.shape)}")
+        B = x.shape[0]
+        cols = []
+        for key, default in (("L_low", None), ("L_high", None), ("omega", 0.0), ("gamma", 1.0)):
+            if key in params:
+                v = params[key]
+                v = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+                cols.append(np.broadcast_to(np.asarray(v, dtype=np.float32).reshape(-1), (B,)))
+            elif default is None:
+                raise KeyError(key)
+            else:
+                cols.append(np.full((B,), default, np.float32))
+        pt = dev.tensor(np.ascontiguousarray(np.stack(cols, axis=1)))
+        out = dev.diff_enhance_f32(x, pt, planar=True, has_omega="omega" in params, has_gamma="gamma" in params)
+        return out.cpu().numpy() if was_numpy else out
+
+    __call__ = forward
+
+    def enhance_image(self, img, params):
+        """``EnhancementPredictor.enhance_image(img, params)`` (use_trained_model.py:83-111) with explicit parameters:
+        ``img`` HxWx3 RGB float in [0, 1], ``params`` a dict of Python floats with ``omega, gamma, L_low, L_high``."""
+        dev = get_device(self.device)
+        x = np.ascontiguousarray(np.asarray(img, dtype=np.float32))
+        if x.ndim != 3 or x.shape[2] != 3:
+            raise ValueError(f"expected an HxWx3 image, got {x.shape}")
+        pt = dev.tensor(np.array([[params["L_low"], params["L_high"], params["omega"], params["gamma"]]], np.float32))
+        out = dev.diff_enhance_f32(dev.tensor(x[None]), pt, planar=False)[0].cpu().numpy()
+        return np.clip(out, 0.0, 1.0)
+
+
 # ------------------------------------------------------------------ float <-> u8 bridging
 def _recover_u8(img):
     """Invert ``u8.astype(float32)/255`` [+ ``color_correction``] exactly; returns (u8 frame, cast kind)."""

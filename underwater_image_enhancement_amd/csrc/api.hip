@@ -395,6 +395,21 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
     return UWIE_OK;
 }
 
+int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, int planar,
+                          const float *d_params, int flags, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && d_out && d_params, "diff_enhance: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE((flags & ~3) == 0, "diff_enhance: flags are UWIE_DIFF_OMEGA | UWIE_DIFF_GAMMA");
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(select_ws_bytes(s));
+    hipStream_t st = (hipStream_t)stream;
+    SelectPlan plan;
+    UWIE_TRY(select_begin_stretch_ranks(s, d_params, 4, d_workspace, st, &plan));
+    UWIE_TRY(select_run(plan, d_img, planar ? 1 : 0, s, false, st));
+    return launch_diff_enhance(d_img, planar ? 1 : 0, s, d_params, flags, (const float *)plan.os, d_out, st);
+}
+
 /* ---------------------------------------------------------------- stage entry points */
 
 int uwie_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int W, int32_t *d_kind, float *d_mean_rgb,

@@ -171,6 +171,7 @@ int launch_percentiles_f32(const float *d_vals, int planar, Shape s, const doubl
 // selection in pieces, for producers that fuse the first histogram sweep (digit = f32_key(v) >> 21, 2048 bins,
 // accumulated into plan.ghist[(b*3 + c) * kSelGroupStride + digit])
 constexpr int kSelGroupStride = 2 * kMaxPct * 2048;
+constexpr int kSelOsStride = 2 * kMaxPct;  // order statistics per (image, channel) in SelectPlan::os
 struct SelectPlan {
     void *state;
     uint32_t *ghist;
@@ -183,6 +184,11 @@ int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
 int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
 int select_lerp_chain(const SelectPlan &plan, Shape s, float eps, float *d_pct4, hipStream_t st);   // [B][3][4]
+// explicit sorted positions per image (vgg_16_UIE.py:78-82): os[bc*8 + 0/1] = sorted[int(L_low/100*n)], sorted[int(L_high/100*n)]
+int select_begin_stretch_ranks(Shape s, const float *d_params, int stride, void *ws, hipStream_t st, SelectPlan *plan);
+// k_diffenh.hip: DifferentiableEnhancement.forward (vgg_16_UIE.py:32-128) after the selection
+int launch_diff_enhance(const float *d_img, int planar, Shape s, const float *d_params, int flags, const float *d_os,
+                        float *d_out, hipStream_t st);
 // float64 data (ES surface): first digit = f64_key(v) >> 53
 int select_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run64(const SelectPlan &plan, const double *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);

@@ -304,6 +304,32 @@ int begin_t(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, 
     return UWIE_OK;
 }
 
+// DifferentiableEnhancement.color_stretch_batch (vgg_16_UIE.py:78-82): per image, the sorted positions
+// int((L/100.0) * n) clamped to [0, n-1] of L_low and L_high, evaluated in float64 like the Python expression
+// (L is the float32 parameter's value).  params[b*stride + 0/1] = L_low, L_high.
+__global__ void k_sel_init_stretch_ranks(SelState<uint32_t> *st, int nbc, const float *__restrict__ params, int stride,
+                                         int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbc) return;
+    const float *pr = params + (size_t)(i / 3) * stride;
+    SelState<uint32_t> s;
+    for (int q = 0; q < kMaxRanks; ++q) {
+        s.prefix[q] = 0;
+        s.gprefix[q] = 0;
+        s.rank[q] = 0;
+        s.gid[q] = 0;
+    }
+    for (int q = 0; q < 2; ++q) {
+        const double pos = ((double)pr[q] / 100.0) * (double)n;
+        long long idx = (long long)pos;  // int(): truncation toward zero
+        idx = idx < 0 ? 0 : idx > n - 1 ? n - 1 : idx;
+        s.rank[q] = (uint32_t)idx;
+    }
+    s.ngroups = 1;
+    st[i] = s;
+}
+
 template <typename V>
 int run_t(const SelectPlan &plan, const V *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st)
 {
@@ -355,6 +381,25 @@ size_t select_ws_bytes(Shape s)
     c.take<uint32_t>(nbc * kMaxRanks * kBins);
     c.take<double>(nbc * kMaxRanks);
     return c.total();
+}
+
+int select_begin_stretch_ranks(Shape s, const float *d_params, int stride, void *ws, hipStream_t st, SelectPlan *plan)
+{
+    const long long n = (long long)s.npx();
+    UWIE_REQUIRE(n >= 1 && n < (1ll << 31), "stretch ranks: plane size out of range");
+    Carver c(ws);
+    const int nbc = s.B * 3;
+    plan->state = c.take<SelState<uint64_t>>(nbc);
+    plan->ghist = c.take<uint32_t>((size_t)nbc * kMaxRanks * kBins);
+    plan->os = c.take<double>((size_t)nbc * kMaxRanks);
+    plan->nq = 1;  // two ranks
+    plan->is64 = false;
+    plan->t[0] = 0.0;
+    UWIE_LAUNCH(k_sel_init_stretch_ranks, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan->state, nbc,
+                d_params, stride, (int)n);
+    UWIE_LAUNCH_CHECK();
+    UWIE_HIP_CHECK(hipMemsetAsync(plan->ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    return UWIE_OK;
 }
 
 int select_begin(Shape s, const double *q, int nq, void *ws, hipStream_t st, SelectPlan *plan)

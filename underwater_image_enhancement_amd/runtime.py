@@ -128,6 +128,20 @@ class Device:
                                            ctypes.cast(p6, ctypes.c_void_p), _ptr(ws), ws.numel(), self.stream()))
         return out, kind
 
+    def diff_enhance_f32(self, img, params, planar: bool, has_omega: bool = True, has_gamma: bool = True):
+        """img: float32 cuda tensor [B,3,H,W] (planar) or [B,H,W,3]; params: float32 [B,4] = L_low, L_high, omega, gamma."""
+        assert img.dtype == torch.float32 and params.dtype == torch.float32 and img.dim() == 4
+        B = img.shape[0]
+        H, W = (img.shape[2], img.shape[3]) if planar else (img.shape[1], img.shape[2])
+        assert img.shape[1 if planar else 3] == 3 and tuple(params.shape) == (B, 4)
+        img, params = img.contiguous(), params.contiguous()
+        ws = self.workspace_for(B, H, W)
+        out = self.empty(tuple(img.shape), torch.float32)
+        check(self.lib.uwie_diff_enhance_f32(self._ctx, _ptr(img), _ptr(out), B, H, W, int(planar), _ptr(params),
+                                             (1 if has_omega else 0) | (2 if has_gamma else 0), _ptr(ws), ws.numel(),
+                                             self.stream()))
+        return out
+
     # ------------------------------------------------------------------ stages
     def cast_classify(self, frames):
         B, H, W = self._bhw(frames)
