@@ -170,6 +170,27 @@ def extras(dev, args, torch, _lib):
     torch.cuda.synchronize()
     res["all_six_strategies_input_megapixels_per_sec"] = round(fan.shape[0] * H * W / 1e6 / (time.perf_counter() - t0), 1)
     del fan
+    # configs[4] on one GPU: 4K frames from pinned host memory and back, copies overlapped with compute (PCIe-inclusive)
+    import underwater_image_enhancement_amd as uw
+
+    chunk, nchunks = 8, 8
+    se = uw.StreamEnhancer(H, W, chunk=chunk, depth=3, strategy=args.strategy)
+    src = synth_frames("underwater", chunk, H, W, dev.torch_device, seed=1000 * 4).cpu()
+    for i in range(se.depth):
+        se.input_slot(i).copy_(src)
+    for warm in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nchunks):
+            if i >= se.depth - 1:
+                se.result()
+            se.input_slot(i)  # (a real producer would write the next frames here)
+            se.submit_slot(i)
+        while se._pending:
+            se.result()
+        dt = time.perf_counter() - t0
+    res["configs4_stream_4k_pinned_host_megapixels_per_sec"] = round(nchunks * chunk * H * W / 1e6 / dt, 1)
+    del se, src
     one = synth_frames("underwater", 1, 1080, 1920, dev.torch_device, seed=1000 * 1)
     ms = timed_enhance(dev, _lib, torch, one, args.strategy, 10)
     res["configs1_1080p_batch1_ms"] = round(ms, 3)
