@@ -135,6 +135,14 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
 int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, int planar,
                           const float *d_params, int flags, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * vgg_16_UIE.extract_all_features (vgg_16_UIE.py:435-466) for uint8 frames: d_features [batch][79] float32 =
+ * {mean, std, min, max, median} of each channel of img = u8/255, then mean(img), std(img), mean(img**2), zeros.
+ * NumPy float32 arithmetic (pairwise sums over 8192-element buffers) reproduced bit for bit.
+ */
+int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_features, int batch, int H, int W,
+                             void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------- per-stage entry points (parity tests, composition) ---------------- */
 
 /* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */

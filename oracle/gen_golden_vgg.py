@@ -53,6 +53,13 @@ def main():
         for k, v in par.items():
             out[f"{tag}/{k}"] = v
         out[f"{tag}/out"] = res
+    # extract_all_features (vgg_16_UIE.py:435-466) on uint8 frames: sizes around the 8192-element buffer boundaries
+    for tag, shape in (("feat_37x53", (37, 53)), ("feat_64x128", (64, 128)), ("feat_91x90", (91, 90)), ("feat_5x7", (5, 7))):
+        u8 = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        if tag == "feat_91x90":
+            u8[:, :, 2] //= 5
+        out[f"{tag}/u8"] = u8
+        out[f"{tag}/features"] = V.extract_all_features(u8)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, len(out), "arrays")
 

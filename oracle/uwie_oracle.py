@@ -484,3 +484,22 @@ def diff_enhance_image(img_hwc, params):
     par = {k: np.array([[float(params[k])]], np.float32) for k in ("omega", "gamma", "L_low", "L_high")}
     out = diff_enhance(np.ascontiguousarray(x.transpose(2, 0, 1))[None], par)[0].transpose(1, 2, 0)
     return np.clip(out, 0.0, 1.0)
+
+
+def extract_all_features(img):
+    """vgg_16_UIE.extract_all_features, vgg_16_UIE.py:435-466 (with _ensure_float01, :417-427)."""
+    img = np.asarray(img)
+    if img.dtype == np.uint8:
+        img = img.astype(np.float32) / 255.0
+    else:
+        img = img.astype(np.float32)
+        if img.max() > 1.0:
+            img = img / 255.0
+    feats = []
+    for c in range(3):
+        ch = img[:, :, c]
+        feats.extend([float(np.mean(ch)), float(np.std(ch)), float(np.min(ch)), float(np.max(ch)), float(np.median(ch))])
+    feats.extend([float(np.mean(img)), float(np.std(img)), float(np.mean(img ** 2))])
+    while len(feats) < 79:
+        feats.append(0.0)
+    return np.array(feats[:79], dtype=np.float32)

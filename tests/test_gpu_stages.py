@@ -321,7 +321,7 @@ def test_diff_enhance_matches_reference_outputs_and_oracle(dev, orc):
     from test_oracle_golden import ulp_distance_f32
 
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_stages.npz"))
-    tags = sorted({k.split("/")[0] for k in z.files})
+    tags = sorted({k.split("/")[0] for k in z.files if not k.startswith("feat_")})
     enh = uw.DifferentiableEnhancement()
     for tag in tags:
         par = {k: z[f"{tag}/{k}"] for k in ("L_low", "L_high", "omega", "gamma") if f"{tag}/{k}" in z.files}
@@ -346,3 +346,28 @@ def test_diff_enhance_matches_reference_outputs_and_oracle(dev, orc):
     hwc = np.ascontiguousarray(img[0].transpose(1, 2, 0))
     p1 = {"L_low": 7.5, "L_high": 91.0, "omega": 0.35, "gamma": 0.6}
     assert ulp_distance_f32(enh.enhance_image(hwc, p1), orc.diff_enhance_image(hwc, p1)).max() <= 1
+
+
+# ------------------------------------------------------------------ vgg_16_UIE.extract_all_features (N4)
+def test_extract_all_features_bit_exact(dev, orc):
+    """uwie_extract_features_u8 against the reference function's outputs (goldens) and the NumPy oracle on further
+    sizes: ragged buffers, a single full 8192 buffer, odd and even pixel counts, a batch.  Bit-exact."""
+    import os
+
+    import underwater_image_enhancement_amd as uw
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_stages.npz"))
+    for tag in sorted({k.split("/")[0] for k in z.files if k.startswith("feat_")}):
+        got = uw.extract_all_features(z[f"{tag}/u8"])
+        assert got.shape == (79,) and got.dtype == np.float32
+        same(got, z[f"{tag}/features"])
+    rng = np.random.default_rng(64)
+    for shape in ((64, 128), (211, 157), (480, 640), (33, 83), (128, 64)):
+        u8 = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+        u8[: shape[0] // 3] //= 3
+        same(uw.extract_all_features(u8), orc.extract_all_features(u8))
+    batch = rng.integers(0, 256, (3, 70, 90, 3), dtype=np.uint8)
+    got = uw.extract_all_features(batch)
+    assert got.shape == (3, 79)
+    for b in range(3):
+        same(got[b], orc.extract_all_features(batch[b]))

@@ -67,7 +67,7 @@ def _vgg_cases():
     import os
 
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_stages.npz"))
-    tags = sorted({k.split("/")[0] for k in z.files})
+    tags = sorted({k.split("/")[0] for k in z.files if not k.startswith("feat_")})
     return z, tags
 
 
@@ -93,3 +93,15 @@ def test_diff_enhance_oracle_matches_the_reference_module():
             assert ulp_distance_f32(got, want).max() <= 1, tag
         else:
             assert np.array_equal(got, want), tag
+
+
+def test_extract_all_features_oracle_matches_the_reference_function():
+    from oracle import uwie_oracle as orc
+
+    z, _ = _vgg_cases()
+    tags = sorted({k.split("/")[0] for k in z.files if k.startswith("feat_")})
+    assert len(tags) == 4
+    for tag in tags:
+        got = orc.extract_all_features(z[f"{tag}/u8"])
+        assert got.dtype == np.float32 and got.shape == (79,)
+        assert np.array_equal(got, z[f"{tag}/features"]), tag

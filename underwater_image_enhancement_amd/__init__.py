@@ -5,9 +5,9 @@ fails loudly when it (or a ROCm device) is missing -- there is no CPU fallback.
 """
 from ._lib import UwieError, UwieParams, build, load  # noqa: F401
 from .api import (DRIVER_STRATEGIES, DifferentiableEnhancement, EnhancementStrategies, SixStrategies, color_correction,  # noqa: F401
-                  detect_image_type, enhance, enhance_all, process_batch)
+                  detect_image_type, enhance, enhance_all, extract_all_features, process_batch)
 from .runtime import Device, get_device  # noqa: F401
 from .streaming import StreamEnhancer  # noqa: F401
 
-__all__ = ["enhance", "enhance_all", "process_batch", "DRIVER_STRATEGIES", "DifferentiableEnhancement", "SixStrategies", "EnhancementStrategies", "detect_image_type", "color_correction", "Device",
+__all__ = ["enhance", "enhance_all", "process_batch", "extract_all_features", "DRIVER_STRATEGIES", "DifferentiableEnhancement", "SixStrategies", "EnhancementStrategies", "detect_image_type", "color_correction", "Device",
            "get_device", "StreamEnhancer", "UwieError", "UwieParams", "build", "load"]

@@ -161,6 +161,17 @@ class DifferentiableEnhancement:
         return np.clip(out, 0.0, 1.0)
 
 
+def extract_all_features(img, device: int | None = None):
+    """``vgg_16_UIE.extract_all_features(img)`` (vgg_16_UIE.py:435-466) for a uint8 RGB frame ``[H,W,3]`` (returns the
+    reference's ``(79,)`` float32 vector) or a batch ``[B,H,W,3]`` (returns ``(B, 79)``).  Float inputs of the reference
+    (``_ensure_float01``) are not taken here: pass the decoded uint8 frame."""
+    dev = get_device(device)
+    if not hasattr(img, "data_ptr") and np.asarray(img).dtype != np.uint8:
+        raise ValueError("extract_all_features on the device takes uint8 frames")
+    batch, was_numpy, single = _as_batch_u8(img, dev)
+    return _finish(dev.extract_features_u8(batch), was_numpy, single)
+
+
 # ------------------------------------------------------------------ float <-> u8 bridging
 def _recover_u8(img):
     """Invert ``u8.astype(float32)/255`` [+ ``color_correction``] exactly; returns (u8 frame, cast kind)."""

@@ -334,6 +334,8 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
     size_t stage = canny_ws_bytes(s) + (size_t)batch * sizeof(Region) + 256;
     const size_t gf = guided_ws_bytes(s);
     if (gf > stage) stage = gf;
+    const size_t ft = features_ws_bytes(s);
+    if (ft > stage) stage = ft;
     const size_t cl = clahe_ws_bytes(s, p && p->tiles_x > 0 ? p->tiles_x : 8, p && p->tiles_y > 0 ? p->tiles_y : 8);
     if (cl > stage) stage = cl;
     const size_t al = airlight_ws_bytes(s) + (size_t)batch * s.npx() + 256;
@@ -408,6 +410,16 @@ int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int b
     UWIE_TRY(select_begin_stretch_ranks(s, d_params, 4, d_workspace, st, &plan));
     UWIE_TRY(select_run(plan, d_img, planar ? 1 : 0, s, false, st));
     return launch_diff_enhance(d_img, planar ? 1 : 0, s, d_params, flags, (const float *)plan.os, d_out, st);
+}
+
+int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_features, int batch, int H, int W,
+                             void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_features, "extract_features: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(features_ws_bytes(s));
+    return launch_features_u8(d_in, s, d_features, d_workspace, (hipStream_t)stream);
 }
 
 /* ---------------------------------------------------------------- stage entry points */

@@ -145,6 +145,16 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
                  int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st);
 int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st);
 
+// k_airlight.hip: NumPy-order sum / mean / sum of squared deviations per region and channel
+int launch_region_stats(const uint8_t *d_in, const int32_t *d_kind, const Region *d_regs, int nreg, int max_rows,
+                        int max_cols, Shape s, float *csum, int maxChunks, float *tot, float *mean, float *vtot,
+                        hipStream_t st);
+// k_codes.hip: hist[b][c][256] += counts of the u8 frame (caller zeroes)
+int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_t st);
+// k_features.hip: vgg_16_UIE.extract_all_features (79 floats per image)
+size_t features_ws_bytes(Shape s);
+int launch_features_u8(const uint8_t *d_in, Shape s, float *d_out, void *ws, hipStream_t st);
+
 // k_guided.hip
 size_t guided_ws_bytes(Shape s);
 size_t box_ws_bytes(Shape s);

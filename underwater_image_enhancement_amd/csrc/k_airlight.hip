@@ -11,14 +11,12 @@
 // enumerates the recursion's leaves first and combines them in post-order.
 #include "common.h"
 #include "devutil.h"
+#include "pairwise_tree.h"
 
 namespace uwie {
 
 namespace {
 
-constexpr int kNpChunk = 8192;  // NumPy's reduction buffer size (np.getbufsize())
-constexpr int kMaxLeaves = 192;   // a leaf of the pairwise recursion holds 64..128 elements: at most 127 per 8192-element chunk
-constexpr int kTreeLevels = 10;    // depth of that recursion for n < 8192 is at most 8
 constexpr int kMaxLevels = 32;
 
 struct TraceRec {  // matches the layout documented in uwie.h
@@ -77,11 +75,6 @@ struct Elem {
         return v;
     }
 };
-
-__device__ __forceinline__ float tree8(const float *r)
-{
-    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-}
 
 // NumPy's pairwise_sum on a block of n <= 128 elements starting at raster element e0, three channels at once.
 template <bool VAR>
@@ -204,9 +197,7 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     const int len = min(kNpChunk, n - c0);
 
     __shared__ float xs[256];
-    __shared__ uint16_t lvOff[kTreeLevels + 1][kMaxLeaves], lvLen[kTreeLevels + 1][kMaxLeaves], lvChild[kTreeLevels][kMaxLeaves];
-    __shared__ int lvCnt[kTreeLevels + 1];
-    __shared__ float val[2][3][kMaxLeaves];
+    __shared__ PairwiseTree tree;
     for (int i = lane; i < 256; i += 64) xs[i] = px_norm(i);
     __syncthreads();
 
@@ -235,64 +226,10 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
         if (lane == 0) { out[0] = s[0]; out[1] = s[1]; out[2] = s[2]; }
         return;
     }
-    // Ragged chunk: NumPy's recursion splits n > 128 into n2 = n/2 - (n/2)%8 and n - n2.  The tree is expanded level by
-    // level with every lane working (a node list per level, kept in left-to-right order: a split node is replaced by
-    // its two children in place), leaves are summed one per lane, and the sums are folded back level by level
-    // (value = left + right, as the recursion returns them).
-    int nlev = 0;
-    if (lane == 0) { lvOff[0][0] = 0; lvLen[0][0] = (uint16_t)len; lvCnt[0] = 1; }
-    __syncthreads();
-    for (;;) {
-        const int cnt = lvCnt[nlev];
-        int carry = 0;
-        bool any = false;
-        for (int b0 = 0; b0 < cnt; b0 += 64) {
-            const int i = b0 + lane;
-            const int l = i < cnt ? lvLen[nlev][i] : 0, off = i < cnt ? lvOff[nlev][i] : 0;
-            const bool split = l > 128;
-            const uint32_t kids = i < cnt ? (split ? 2u : 1u) : 0u;
-            const uint32_t incl = wave_incl_scan_u32(kids);
-            const int pos = carry + (int)(incl - kids);
-            if (i < cnt) {
-                lvChild[nlev][i] = (uint16_t)pos;
-                if (split) {
-                    int n2 = l / 2;
-                    n2 -= n2 % 8;
-                    lvOff[nlev + 1][pos] = (uint16_t)off; lvLen[nlev + 1][pos] = (uint16_t)n2;
-                    lvOff[nlev + 1][pos + 1] = (uint16_t)(off + n2); lvLen[nlev + 1][pos + 1] = (uint16_t)(l - n2);
-                } else {
-                    lvOff[nlev + 1][pos] = (uint16_t)off; lvLen[nlev + 1][pos] = (uint16_t)l;
-                }
-            }
-            carry += (int)__shfl(incl, 63);
-            any = any || __any(split);
-        }
-        if (!any) break;  // level `nlev` holds only leaves
-        if (lane == 0) lvCnt[nlev + 1] = carry;
-        ++nlev;
-        __syncthreads();
-    }
-    const int nLeaf = lvCnt[nlev];
-    for (int i = lane; i < nLeaf; i += 64) {
-        float s[3];
-        leaf_sum3<VAR>(el, r, c0 + lvOff[nlev][i], lvLen[nlev][i], s);
-        val[nlev & 1][0][i] = s[0]; val[nlev & 1][1][i] = s[1]; val[nlev & 1][2][i] = s[2];
-    }
-    __syncthreads();
-    for (int lv = nlev - 1; lv >= 0; --lv) {
-        const int cnt = lvCnt[lv];
-        for (int i = lane; i < cnt; i += 64) {
-            const int ch = lvChild[lv][i];
-            const bool split = lvLen[lv][i] > 128;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float a = val[(lv + 1) & 1][c][ch];
-                val[lv & 1][c][i] = split ? a + val[(lv + 1) & 1][c][ch + 1] : a;
-            }
-        }
-        __syncthreads();
-    }
-    if (lane == 0) { out[0] = val[0][0][0]; out[1] = val[0][1][0]; out[2] = val[0][2][0]; }
+    // ragged chunk: the recursion tree of NumPy's pairwise sum for this length (pairwise_tree.h)
+    float res[3];
+    pairwise_ragged(len, lane, tree, [&](int off, int l, float *s3) { leaf_sum3<VAR>(el, r, c0 + off, l, s3); }, res);
+    if (lane == 0) { out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; }
 }
 
 // Sequential accumulation of the chunk sums (NumPy adds each buffer's pairwise result into the running total),
@@ -394,6 +331,26 @@ LevelBufs carve_level(Carver &c, Shape s)
 }
 
 }  // namespace
+
+// np.sum / np.mean / np.var arithmetic of block[:, :, c] for a list of regions (see k_q_chunk_sums / k_q_combine):
+// tot[reg*3+c] = sum, mean[...] = float32(float64(sum)/n), vtot[...] = sum of (x - mean)^2.  csum: scratch of
+// nreg * maxChunks * 3 floats with maxChunks >= ceil(max_rows * max_cols / 8192).
+int launch_region_stats(const uint8_t *d_in, const int32_t *d_kind, const Region *d_regs, int nreg, int max_rows,
+                        int max_cols, Shape s, float *csum, int maxChunks, float *tot, float *mean, float *vtot,
+                        hipStream_t st)
+{
+    const int nch = cdiv((long long)max_rows * max_cols, kNpChunk);
+    UWIE_REQUIRE(nch <= maxChunks, "region_stats: scratch too small");
+    UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, tot, mean);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, vtot, mean);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
 
 size_t airlight_ws_bytes(Shape s)
 {

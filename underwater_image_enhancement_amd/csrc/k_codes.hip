@@ -441,6 +441,13 @@ size_t codes_ws_bytes(Shape s, int tx, int ty)
 }
 
 // The five strategies that live in the code domain.  `f64` selects the ES arithmetic (float64 after the first
+int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_t st)
+{
+    UWIE_LAUNCH(k_frame_hist, dim3(grid_for(s.npx(), 1024), s.B), dim3(256), 0, st, d_in, (int)s.npx(), d_hist);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
 // u8 quantisation, eps 1e-10, gamma = clip(x**(1/g))); otherwise S6 arithmetic (float32, eps 1e-6, x**g).
 int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
                          uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st)

@@ -1,0 +1,89 @@
+// NumPy's float32 summation order, shared by the quadtree statistics (k_airlight.hip) and the feature statistics
+// (k_features.hip).  np.add.reduce walks its input in buffers of 8192 elements (np.getbufsize()); every buffer is summed
+// by pairwise_sum -- n < 8: sequential; n <= 128: eight interleaved accumulators, combined as a 3-level tree, then the
+// tail sequentially; n > 128: split at n2 = n/2 - (n/2)%8 and add the two halves -- and the buffer results are added to
+// the running total one after the other.
+#pragma once
+#include "devutil.h"
+
+namespace uwie {
+
+constexpr int kNpChunk = 8192;     // NumPy's reduction buffer size
+constexpr int kMaxLeaves = 192;    // a leaf of the pairwise recursion holds 64..128 elements: at most 127 per chunk
+constexpr int kTreeLevels = 10;    // depth of that recursion for n < 8192 is at most 8
+
+struct PairwiseTree {  // LDS scratch of one wavefront
+    uint16_t off[kTreeLevels + 1][kMaxLeaves], len[kTreeLevels + 1][kMaxLeaves], child[kTreeLevels][kMaxLeaves];
+    int cnt[kTreeLevels + 1];
+    float val[2][3][kMaxLeaves];
+};
+
+// Three sums at once over a ragged chunk of `len` < 8192 elements, one wavefront (blockDim.x == 64, all lanes call).
+// The tree is expanded level by level with every lane working (a node list per level, kept in left-to-right order: a
+// split node is replaced by its two children in place), leaves are summed one per lane by `leaf(off, len, out3)`, and
+// the sums are folded back level by level (value = left + right, as the recursion returns them).  Result in lane 0.
+template <class Leaf>
+__device__ void pairwise_ragged(int len, int lane, PairwiseTree &t, Leaf leaf, float res[3])
+{
+    int nlev = 0;
+    if (lane == 0) { t.off[0][0] = 0; t.len[0][0] = (uint16_t)len; t.cnt[0] = 1; }
+    __syncthreads();
+    for (;;) {
+        const int cnt = t.cnt[nlev];
+        int carry = 0;
+        bool any = false;
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+            const int i = b0 + lane;
+            const int l = i < cnt ? t.len[nlev][i] : 0, off = i < cnt ? t.off[nlev][i] : 0;
+            const bool split = l > 128;
+            const uint32_t kids = i < cnt ? (split ? 2u : 1u) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(kids);
+            const int pos = carry + (int)(incl - kids);
+            if (i < cnt) {
+                t.child[nlev][i] = (uint16_t)pos;
+                if (split) {
+                    int n2 = l / 2;
+                    n2 -= n2 % 8;
+                    t.off[nlev + 1][pos] = (uint16_t)off; t.len[nlev + 1][pos] = (uint16_t)n2;
+                    t.off[nlev + 1][pos + 1] = (uint16_t)(off + n2); t.len[nlev + 1][pos + 1] = (uint16_t)(l - n2);
+                } else {
+                    t.off[nlev + 1][pos] = (uint16_t)off; t.len[nlev + 1][pos] = (uint16_t)l;
+                }
+            }
+            carry += (int)__shfl(incl, 63);
+            any = any || __any(split);
+        }
+        if (!any) break;  // level `nlev` holds only leaves
+        if (lane == 0) t.cnt[nlev + 1] = carry;
+        ++nlev;
+        __syncthreads();
+    }
+    const int nLeaf = t.cnt[nlev];
+    for (int i = lane; i < nLeaf; i += 64) {
+        float s[3];
+        leaf(t.off[nlev][i], t.len[nlev][i], s);
+        t.val[nlev & 1][0][i] = s[0]; t.val[nlev & 1][1][i] = s[1]; t.val[nlev & 1][2][i] = s[2];
+    }
+    __syncthreads();
+    for (int lv = nlev - 1; lv >= 0; --lv) {
+        const int cnt = t.cnt[lv];
+        for (int i = lane; i < cnt; i += 64) {
+            const int ch = t.child[lv][i];
+            const bool split = t.len[lv][i] > 128;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float a = t.val[(lv + 1) & 1][c][ch];
+                t.val[lv & 1][c][i] = split ? a + t.val[(lv + 1) & 1][c][ch + 1] : a;
+            }
+        }
+        __syncthreads();
+    }
+    res[0] = t.val[0][0][0]; res[1] = t.val[0][1][0]; res[2] = t.val[0][2][0];
+}
+
+__device__ __forceinline__ float tree8(const float *r)
+{
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+}  // namespace uwie

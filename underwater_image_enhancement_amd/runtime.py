@@ -142,6 +142,16 @@ class Device:
                                              self.stream()))
         return out
 
+    def extract_features_u8(self, frames):
+        """frames: uint8 cuda tensor [B,H,W,3] -> float32 [B,79] (vgg_16_UIE.extract_all_features per frame)."""
+        B, H, W = self._bhw(frames)
+        assert frames.dtype == torch.uint8
+        ws = self.workspace_for(B, H, W)
+        out = self.empty((B, 79), torch.float32)
+        check(self.lib.uwie_extract_features_u8(self._ctx, _ptr(frames), _ptr(out), B, H, W, _ptr(ws), ws.numel(),
+                                                self.stream()))
+        return out
+
     # ------------------------------------------------------------------ stages
     def cast_classify(self, frames):
         B, H, W = self._bhw(frames)
