@@ -143,6 +143,18 @@ int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int b
 int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_features, int batch, int H, int W,
                              void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * QualityAssessment.comprehensive_assessment (quality_assessment.py:215-286; called on every strategy output by
+ * main.py:130-146 to pick the best one).  d_u8: the quantised frame (img*255).astype(uint8), [batch][H][W][3];
+ * d_f32 (optional): the float image itself, used by the colourfulness score only (NULL: u8/255 is used).
+ * weights8 (host pointer, optional): weights in the order contrast, sharpness, entropy, saturation, brightness,
+ * edge_density, colorfulness, naturalness (NULL: the reference defaults).  d_scores: [batch][9] float64 = the eight
+ * scores in that order, then the weighted total.  Integer-derived parts are exact; float statistics are evaluated in
+ * float64 (NumPy: float32 pairwise): 2e-3 on the 0..100 scores.
+ */
+int uwie_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, int batch, int H, int W, int gray_shift,
+                        const double *weights8, double *d_scores, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------- per-stage entry points (parity tests, composition) ---------------- */
 
 /* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */

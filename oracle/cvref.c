@@ -481,3 +481,36 @@ void cvref_equalize_hist_u8(const uint8_t *src, uint8_t *dst, size_t n)
     }
     for (size_t k = 0; k < n; ++k) dst[k] = lut[src[k]];
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * cvtColor(u8, COLOR_RGB2HSV), 8-bit, hue range 180 (OpenCV 4.x RGB2HSV_b): v = max, s = (diff * sdiv[v] + 2^11) >> 12
+ * with sdiv[i] = saturate_cast<int>((255 << 12) / (1. * i)) (cvRound of the double quotient), h in [0, 180).
+ * Used by quality_assessment.py:79,192 (saturation channel only).  PARITY UNPINNED (no OpenCV here), KAT-tested. */
+void cvref_rgb2hsv_u8(const uint8_t *src, uint8_t *dst, size_t n)
+{
+    static int sdiv[256], hdiv[256], init = 0;
+    const int hsv_shift = 12, hr = 180;
+    if (!init) {
+        sdiv[0] = hdiv[0] = 0;
+        for (int i = 1; i < 256; ++i) {
+            sdiv[i] = (int)lrint((255 << hsv_shift) / (1. * i));
+            hdiv[i] = (int)lrint((hr << hsv_shift) / (6. * i));
+        }
+        init = 1;
+    }
+    for (size_t p = 0; p < n; ++p) {
+        const int r = src[3 * p], g = src[3 * p + 1], b = src[3 * p + 2];
+        int v = r > g ? r : g; v = v > b ? v : b;
+        int vmin = r < g ? r : g; vmin = vmin < b ? vmin : b;
+        const int diff = v - vmin;
+        const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+        const int s = (diff * sdiv[v] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+        h = (h * hdiv[diff] + (1 << (hsv_shift - 1))) >> hsv_shift;
+        h += h < 0 ? hr : 0;
+        dst[3 * p] = (uint8_t)h;
+        dst[3 * p + 1] = (uint8_t)s;
+        dst[3 * p + 2] = (uint8_t)v;
+    }
+}

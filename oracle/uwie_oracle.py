@@ -118,6 +118,20 @@ def cv_canny_u8(plane, low, high):
     return dst
 
 
+def cv_rgb2hsv_u8(rgb):
+    src = np.ascontiguousarray(rgb, dtype=np.uint8)
+    dst = np.empty_like(src)
+    _cv().cvref_rgb2hsv_u8(_p(src), _p(dst), src.size // 3)
+    return dst
+
+
+def cv_laplacian_f64(gray_f32):
+    """cv2.Laplacian(gray, CV_64F) with the default ksize=1: kernel [[0,1,0],[1,-4,1],[0,1,0]], BORDER_REFLECT_101,
+    accumulated in float64 (filter2D).  PARITY UNPINNED."""
+    g = np.pad(np.asarray(gray_f32, dtype=np.float64), 1, mode="reflect")
+    return g[:-2, 1:-1] + g[2:, 1:-1] + g[1:-1, :-2] + g[1:-1, 2:] - 4.0 * g[1:-1, 1:-1]
+
+
 def cv_equalize_hist_u8(plane):
     src = np.ascontiguousarray(plane, dtype=np.uint8)
     dst = np.empty_like(src)
@@ -503,3 +517,48 @@ def extract_all_features(img):
     while len(feats) < 79:
         feats.append(0.0)
     return np.array(feats[:79], dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# quality_assessment.QualityAssessment: the eight no-reference scores and their weighted
+# sum, restated line by line on the oracle's OpenCV restatements.  skimage.measure.shannon_entropy is restated from
+# its published definition: -sum(p * log2(p)) over the relative frequencies of the distinct values (scipy.stats.entropy).
+QUALITY_KEYS = ("contrast", "sharpness", "entropy", "saturation", "brightness", "edge_density", "colorfulness", "naturalness")
+QUALITY_WEIGHTS = {"contrast": 0.20, "sharpness": 0.20, "entropy": 0.15, "saturation": 0.15, "brightness": 0.10,
+                   "edge_density": 0.10, "colorfulness": 0.05, "naturalness": 0.05}  # quality_assessment.py:229-238
+
+
+def quality_scores(img, gray_shift=GRAY_SHIFT_DEFAULT):
+    """QualityAssessment.assess_* (quality_assessment.py:15-212) of a float RGB image in [0, 1]; returns the dict."""
+    img = np.asarray(img)
+    u8 = (img * 255).astype(np.uint8)
+    gray_u8 = cv_rgb2gray_u8(u8, gray_shift)
+    gray = gray_u8.astype(np.float32) / 255.0
+    sc = {}
+    sc["contrast"] = np.clip(np.std(gray) / 0.5 * 100, 0, 100)                                     # :25-31
+    sc["sharpness"] = np.clip(np.var(cv_laplacian_f64(gray)) / 0.5 * 100, 0, 100)                  # :45-52
+    _, counts = np.unique(gray, return_counts=True)
+    pk = counts / counts.sum()
+    entropy = -np.sum(pk * np.log(pk)) / np.log(2)
+    sc["entropy"] = np.clip((entropy - 4) / 4 * 100, 0, 100)                                       # :66-73
+    hsv = cv_rgb2hsv_u8(u8).astype(np.float32) / 255.0
+    sc["saturation"] = np.clip(np.mean(hsv[:, :, 1]) * 100, 0, 100)                                # :87-94
+    L = cv_rgb2lab_u8(u8).astype(np.float32)[:, :, 0]
+    sc["brightness"] = 100 - np.clip(abs(np.mean(L) - 128) / 128 * 100, 0, 100)                    # :108-117
+    edges = cv_canny_u8(gray_u8, 50, 150)
+    sc["edge_density"] = np.clip(np.sum(edges > 0) / edges.size / 0.2 * 100, 0, 100)               # :131-140
+    R, G, B = img[:, :, 0], img[:, :, 1], img[:, :, 2]
+    rg, yb = R - G, 0.5 * (R + G) - B
+    colorfulness = np.sqrt(np.std(rg) ** 2 + np.std(yb) ** 2) + 0.3 * np.sqrt(np.mean(rg) ** 2 + np.mean(yb) ** 2)
+    sc["colorfulness"] = np.clip(colorfulness / 0.5 * 100, 0, 100)                                 # :154-175
+    unnatural = (np.sum(hsv[:, :, 1] > 0.9) / hsv[:, :, 1].size + np.sum(gray < 0.1) / gray.size
+                 + np.sum(gray > 0.9) / gray.size)
+    sc["naturalness"] = 100 - np.clip(unnatural * 200, 0, 100)                                     # :189-205
+    return sc
+
+
+def quality_assessment(img, weights=None, gray_shift=GRAY_SHIFT_DEFAULT):
+    """comprehensive_assessment (quality_assessment.py:215-286): (total, scores)."""
+    weights = QUALITY_WEIGHTS if weights is None else weights
+    scores = quality_scores(img, gray_shift)
+    return sum(scores[k] * weights.get(k, 0) for k in scores), scores

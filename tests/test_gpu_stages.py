@@ -371,3 +371,41 @@ def test_extract_all_features_bit_exact(dev, orc):
     assert got.shape == (3, 79)
     for b in range(3):
         same(got[b], orc.extract_all_features(batch[b]))
+
+
+# ------------------------------------------------------------------ quality_assessment.QualityAssessment (N2)
+def test_quality_scores_match_oracle(dev, orc):
+    """uwie_quality_scores against the oracle's restatement of quality_assessment.py.  edge_density and naturalness are
+    integer-derived (exact up to float64 rounding); the others are float32 NumPy statistics that the device evaluates in
+    float64: tolerance 2e-3 on the 0..100 scale."""
+    import underwater_image_enhancement_amd as uw
+
+    rng = np.random.default_rng(2025)
+    yy, xx = np.mgrid[0:96, 0:130]
+    smooth = 0.5 + 0.3 * np.sin(xx / 17.0) * np.cos(yy / 11.0)
+    images = {
+        "random": rng.random((96, 130, 3)),
+        "dark": rng.random((96, 130, 3)) * 0.3,
+        "bright": 0.7 + rng.random((96, 130, 3)) * 0.3,
+        "flat": np.full((64, 64, 3), 0.5),
+        "binary": rng.choice([0.0, 1.0], size=(70, 90, 3)),
+        "smooth": np.clip(smooth[:, :, None] * np.array([0.5, 0.8, 0.9]) + rng.normal(0, 0.01, (96, 130, 3)), 0, 1),
+    }
+    for name, img in images.items():
+        img = img.astype(np.float32)
+        total, scores = uw.QualityAssessment.comprehensive_assessment(img)
+        wtotal, want = orc.quality_assessment(img)
+        assert list(scores) == list(uw.QUALITY_KEYS)
+        for k in uw.QUALITY_KEYS:
+            tol = 1e-9 if k in ("edge_density", "naturalness") else 2e-3
+            assert abs(scores[k] - float(want[k])) <= tol, (name, k, scores[k], float(want[k]))
+        assert abs(total - float(wtotal)) <= 2e-3, (name, total, float(wtotal))
+    # batch form on the enhancement outputs, custom weights
+    u8 = (images["smooth"].astype(np.float32) * 255).astype(np.uint8)
+    batch = np.stack([u8, u8[::-1].copy()])
+    w = {"contrast": 0.5, "entropy": 0.5}
+    got = uw.quality_scores(batch, weights=w)
+    assert got.shape == (2, 9)
+    for b in range(2):
+        wt, sc = orc.quality_assessment(batch[b].astype(np.float32) / 255.0, weights=w)
+        assert abs(got[b, 8] - float(wt)) <= 2e-3

@@ -209,3 +209,18 @@ def test_full_strategies_run_and_stay_in_range():
         assert y.shape == x.shape and y.min() >= 0 and y.max() <= 1
     with pytest.raises(ValueError):
         orc.DictStrategyOracle.apply_strategy(x, "nope", {})
+
+
+def test_rgb2hsv_kats_and_laplacian():
+    """cvref_rgb2hsv_u8 (quality_assessment.py:79): hand-derived values of OpenCV's 8-bit formula, h in [0,180);
+    Laplacian of a constant is 0 and of a paraboloid x^2 + y^2 is 4 in the interior."""
+    from oracle import uwie_oracle as orc
+
+    px = np.array([[[255, 0, 0], [128, 128, 128], [200, 100, 50], [0, 255, 0], [0, 0, 255], [10, 20, 30], [0, 0, 0]]], np.uint8)
+    want = np.array([[[0, 255, 255], [0, 0, 128], [10, 191, 200], [60, 255, 255], [120, 255, 255], [105, 170, 30], [0, 0, 0]]], np.uint8)
+    assert np.array_equal(orc.cv_rgb2hsv_u8(px), want)
+    assert np.all(orc.cv_laplacian_f64(np.full((5, 7), 0.25, np.float32)) == 0.0)
+    yy, xx = np.mgrid[0:9, 0:11].astype(np.float32)
+    lap = orc.cv_laplacian_f64(xx * xx + yy * yy)
+    assert np.all(lap[1:-1, 1:-1] == 4.0)
+    assert lap[0, 5] == 2.0 + 2.0  # reflect-101: the row above row 0 is row 1, so d2/dy2 of y^2 at y=0 is 2*(1-0) = 2

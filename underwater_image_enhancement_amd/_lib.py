@@ -66,6 +66,7 @@ SIGNATURES = {
     "uwie_enhance_all_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP],
     "uwie_diff_enhance_f32": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _SZ, _VP],
     "uwie_extract_features_u8": [_VP, _VP, _VP, _I, _I, _I, _VP, _SZ, _VP],
+    "uwie_quality_scores": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP],
     "uwie_cast_classify": [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP],
     "uwie_normalise_correct": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP],
     "uwie_atmospheric_light": [_VP, _VP, _VP, _I, _I, _I, _PP, _VP, _VP, _VP, _SZ, _VP],

@@ -161,6 +161,42 @@ class DifferentiableEnhancement:
         return np.clip(out, 0.0, 1.0)
 
 
+QUALITY_KEYS = ("contrast", "sharpness", "entropy", "saturation", "brightness", "edge_density", "colorfulness", "naturalness")
+
+
+class QualityAssessment:
+    """Mirror of ``quality_assessment.QualityAssessment.comprehensive_assessment`` (quality_assessment.py:215-286)."""
+
+    device: int | None = None
+
+    @classmethod
+    def comprehensive_assessment(cls, img, weights=None):
+        """``img``: HxWx3 RGB float in [0, 1] -> ``(total_score, scores_dict)`` like the reference."""
+        x = np.asarray(img)
+        if x.ndim != 3 or x.shape[2] != 3:
+            raise ValueError(f"expected an HxWx3 image, got {x.shape}")
+        dev = get_device(cls.device)
+        u8 = (x * 255).astype(np.uint8)  # quality_assessment.py:25 etc.: every score starts from this frame
+        w = [weights.get(k, 0) for k in QUALITY_KEYS] if weights is not None else None
+        row = dev.quality_scores(dev.tensor(u8[None]), dev.tensor(np.ascontiguousarray(x[None], dtype=np.float32)), w)
+        row = row[0].cpu().numpy()
+        return float(row[8]), {k: float(row[i]) for i, k in enumerate(QUALITY_KEYS)}
+
+
+def quality_scores(frames_u8, frames_f32=None, weights=None, device: int | None = None):
+    """Batch form on device or host arrays: ``[B,H,W,3]`` uint8 (and optionally the float32 images) -> ``[B,9]`` float64
+    (eight scores in ``QUALITY_KEYS`` order, then the weighted total): best-of-N selection without leaving the GPU."""
+    dev = get_device(device)
+    batch, was_numpy, single = _as_batch_u8(frames_u8, dev)
+    f32 = None
+    if frames_f32 is not None:
+        f32 = frames_f32 if hasattr(frames_f32, "data_ptr") else dev.tensor(np.ascontiguousarray(frames_f32, dtype=np.float32))
+        if f32.dim() == 3:
+            f32 = f32[None]
+    w = [weights.get(k, 0) for k in QUALITY_KEYS] if isinstance(weights, dict) else weights
+    return _finish(dev.quality_scores(batch, f32, w), was_numpy, single)
+
+
 def extract_all_features(img, device: int | None = None):
     """``vgg_16_UIE.extract_all_features(img)`` (vgg_16_UIE.py:435-466) for a uint8 RGB frame ``[H,W,3]`` (returns the
     reference's ``(79,)`` float32 vector) or a batch ``[B,H,W,3]`` (returns ``(B, 79)``).  Float inputs of the reference

@@ -336,6 +336,8 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
     if (gf > stage) stage = gf;
     const size_t ft = features_ws_bytes(s);
     if (ft > stage) stage = ft;
+    const size_t qa = quality_ws_bytes(s);
+    if (qa > stage) stage = qa;
     const size_t cl = clahe_ws_bytes(s, p && p->tiles_x > 0 ? p->tiles_x : 8, p && p->tiles_y > 0 ? p->tiles_y : 8);
     if (cl > stage) stage = cl;
     const size_t al = airlight_ws_bytes(s) + (size_t)batch * s.npx() + 256;
@@ -420,6 +422,19 @@ int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_featur
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(features_ws_bytes(s));
     return launch_features_u8(d_in, s, d_features, d_workspace, (hipStream_t)stream);
+}
+
+int uwie_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, int batch, int H, int W, int gray_shift,
+                        const double *weights8, double *d_scores, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_u8 && d_scores, "quality_scores: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(gray_shift == 14 || gray_shift == 15, "gray_shift must be 14 or 15");
+    static const double kDefault[8] = {0.20, 0.20, 0.15, 0.15, 0.10, 0.10, 0.05, 0.05};  // quality_assessment.py:229-238
+    const Shape s{batch, H, W};
+    UWIE_CHECK_WS(quality_ws_bytes(s));
+    return launch_quality_scores(ctx, d_u8, d_f32, s, gray_shift, weights8 ? weights8 : kDefault, d_scores, d_workspace,
+                                 (hipStream_t)stream);
 }
 
 /* ---------------------------------------------------------------- stage entry points */

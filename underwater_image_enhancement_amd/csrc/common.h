@@ -155,6 +155,11 @@ int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_
 size_t features_ws_bytes(Shape s);
 int launch_features_u8(const uint8_t *d_in, Shape s, float *d_out, void *ws, hipStream_t st);
 
+// k_quality.hip: quality_assessment.QualityAssessment scores, [B][9] float64 (8 scores + weighted total)
+size_t quality_ws_bytes(Shape s);
+int launch_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, Shape s, int gray_shift,
+                          const double *weights8, double *d_scores, void *ws, hipStream_t st);
+
 // k_guided.hip
 size_t guided_ws_bytes(Shape s);
 size_t box_ws_bytes(Shape s);

@@ -152,6 +152,21 @@ class Device:
                                                 self.stream()))
         return out
 
+    def quality_scores(self, frames_u8, frames_f32=None, weights=None, gray_shift: int = 15):
+        """frames_u8: uint8 cuda [B,H,W,3] (the quantised image); frames_f32: optional float32 cuda [B,H,W,3];
+        weights: optional 8 floats.  Returns float64 [B,9]: the eight scores (QUALITY_KEYS order) and the total."""
+        B, H, W = self._bhw(frames_u8)
+        assert frames_u8.dtype == torch.uint8
+        if frames_f32 is not None:
+            assert frames_f32.dtype == torch.float32 and tuple(frames_f32.shape) == (B, H, W, 3)
+            frames_f32 = frames_f32.contiguous()
+        ws = self.workspace_for(B, H, W)
+        out = self.empty((B, 9), torch.float64)
+        w = (ctypes.c_double * 8)(*[float(x) for x in weights]) if weights is not None else None
+        check(self.lib.uwie_quality_scores(self._ctx, _ptr(frames_u8), _ptr(frames_f32), B, H, W, int(gray_shift), w,
+                                           _ptr(out), _ptr(ws), ws.numel(), self.stream()))
+        return out
+
     # ------------------------------------------------------------------ stages
     def cast_classify(self, frames):
         B, H, W = self._bhw(frames)
