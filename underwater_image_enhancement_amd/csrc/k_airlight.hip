@@ -235,20 +235,23 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
 // Sequential accumulation of the chunk sums (NumPy adds each buffer's pairwise result into the running total),
 // and for the first pass the mean: float32(float64(sum) / n) as numpy/_core/_methods.py:_mean does for a scalar result.
 template <bool VAR>
-__global__ void k_q_combine(const Region *__restrict__ regs, const float *__restrict__ csum, int nreg, int maxChunks,
-                            float *__restrict__ tot, float *__restrict__ mean)
+__global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ regs, const float *__restrict__ csum, int nreg,
+                                                  int maxChunks, float *__restrict__ tot, float *__restrict__ mean)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nreg * 3) return;
-    const int reg = i / 3, c = i % 3;
+    // one wavefront per region: the chunk sums come into LDS with coalesced loads, lanes 0..2 then add them in order
+    extern __shared__ float cs[];
+    const int reg = blockIdx.x, lane = threadIdx.x;
     const Region r = regs[reg];
     const int n = r.rows * r.cols;
     if (n == 0) return;
     const int nch = (n + kNpChunk - 1) / kNpChunk;
+    for (int i = lane; i < nch * 3; i += 64) cs[i] = csum[(size_t)reg * maxChunks * 3 + i];
+    __syncthreads();
+    if (lane >= 3) return;
     float acc = 0.0f;
-    for (int k = 0; k < nch; ++k) acc = acc + csum[((size_t)reg * maxChunks + k) * 3 + c];
-    tot[i] = acc;
-    if (!VAR) mean[i] = (float)((double)acc / (double)n);
+    for (int k = 0; k < nch; ++k) acc = acc + cs[k * 3 + lane];
+    tot[reg * 3 + lane] = acc;
+    if (!VAR) mean[reg * 3 + lane] = (float)((double)acc / (double)n);
 }
 
 // compute_Q's final arithmetic (six_stadigy.py:134-155) and the greedy step (six_stadigy.py:100-111).
@@ -343,11 +346,11 @@ int launch_region_stats(const uint8_t *d_in, const int32_t *d_kind, const Region
     UWIE_REQUIRE(nch <= maxChunks, "region_stats: scratch too small");
     UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, tot, mean);
+    UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, tot, mean);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, vtot, mean);
+    UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, vtot, mean);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -380,13 +383,13 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
         UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum);
         UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_combine<false>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+        UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, L.regs, L.csum, nreg,
                            maxChunks, L.tot, L.mean);
         UWIE_LAUNCH_CHECK();
         UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum);
         UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_combine<true>, dim3(cdiv(nreg * 3, 64)), dim3(64), 0, st, L.regs, L.csum, nreg,
+        UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, L.regs, L.csum, nreg,
                            maxChunks, L.vtot, L.mean);
         UWIE_LAUNCH_CHECK();
         int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st);
