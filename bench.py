@@ -221,11 +221,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # UWIE_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo for the timing reduction -- exercises the multi-rank control
+    # flow on a one-GPU box (RCCL refuses two ranks on one device); not a measurement.
+    rehearsal = os.environ.get("UWIE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     dev = uw.get_device(local)
@@ -259,7 +267,7 @@ def main():
     rows = dev.profile_rows()
     dev.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev.torch_device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev.torch_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
