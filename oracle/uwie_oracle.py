@@ -19,6 +19,11 @@ are PARITY UNPINNED (no cv2 in this image, no golden outputs in the reference)
 and are held only by hand-derived known-answer tests.  NumPy semantics are
 those of NumPy 2.2.6 (float32 ``np.percentile`` arithmetic, NEP-50 promotion).
 
+The callers either side of the path are restated at the end of the file:
+``diff_enhance`` / ``extract_all_features`` (``vgg_16_UIE.py``; PINNED on outputs of the real module,
+``oracle/gen_golden_vgg.py``) and ``quality_assessment`` (``quality_assessment.py``; PARITY UNPINNED, it runs on the
+OpenCV restatements).
+
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this module.
 """
