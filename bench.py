@@ -32,13 +32,14 @@ PIPELINE_BYTES_PER_PX = 19.0  # five dependent streaming
 # Quadtree kernels run once per level on a block a quarter the size of the previous one: sum = 4/3.
 Q = 4.0 / 3.0
 KERNEL_BYTES_PER_PX = {
-    "k_chunk_hist": 3, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
+    "k_chunk_hist": 3, "k_chunk_ulps": 0, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
     "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_gradnms": (1 + 1) * Q,
-    "k_canny_union": 1 * Q, "k_canny_flat": 1 * Q, "k_canny_mark": 1 * Q, "k_canny_emit": 1 * Q,
+    "k_canny_union": 1 * Q, "k_canny_mark": 1 * Q, "k_canny_emit": 1 * Q,
     "k_trans_init": 3 + 4, "k_guided_fast<TH>": 1 + 4 + 8, "k_guided_wave": 1 + 4 + 8,
     "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
     "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
-    "k_sel_hist<V>": 3 * 4, "k_restore_planar_hist": 3 + 8 + 12, "k_stretch_apply": 12 + 12, "k_quant_rgb2lab": 12 + 3, "k_clahe_lut": 1,
+    "k_sel_hist<V>": 2 * 3 * 4, "k_restore_planar_hist": 3 + 8 + 12, "k_stretch_lab_lut": 12 + 3, "k_clahe_apply_out": 3 + 3,
+    "k_stretch_out": 12 + 3, "k_stretch_apply": 12 + 12, "k_quant_rgb2lab": 12 + 3, "k_clahe_lut": 1,
     "k_clahe_apply": 1 + 1, "k_lab2rgb_f32": 3 + 12, "k_gamma": 12 + 12, "k_quantise": 12 + 3,
     "k_normalise_correct": 3 + 12,
 }
