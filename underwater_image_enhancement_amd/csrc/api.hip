@@ -93,7 +93,9 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
         P.t = c.take<double>(n);
     }
     const int tx = p ? p->tiles_x : 8, ty = p ? p->tiles_y : 8;
-    P.scratch_bytes = max5(cast_ws_bytes(s), dz ? airlight_ws_bytes(s) : 0, dz ? guided_ws_bytes(s) : 0,
+    // the exact-order guided filter materialises six float64 planes; the default kernels keep everything on chip
+    const bool gf_planes = dz && (!p || p->gf_exact || !guided_fast_handles(s, p->gf_ksize));
+    P.scratch_bytes = max5(cast_ws_bytes(s), dz ? airlight_ws_bytes(s) : 0, gf_planes ? guided_ws_bytes(s) : 0,
                            select_ws_bytes(s), clahe_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8));
     const size_t cw = codes_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8);
     if (cw > P.scratch_bytes) P.scratch_bytes = cw;

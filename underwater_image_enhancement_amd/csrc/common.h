@@ -172,6 +172,7 @@ int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, doub
 // k_guided_wave.hip: barrier-free wavefront-per-strip guided filter for k in {10, 15, 20}; *handled = 0 -> not taken
 int launch_guided_wave(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
                        hipStream_t st);
+bool guided_fast_handles(Shape s, int k);
 // k_guided_fast.hip: fused float64 guided filter (free summation order); *handled = 0 -> use launch_guided
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
                        hipStream_t st);

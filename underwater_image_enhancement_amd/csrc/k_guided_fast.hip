@@ -339,6 +339,14 @@ bool fits(const FastGeom &g, int TH)
 
 }  // namespace
 
+// Whether launch_guided_fast will take this (shape, window) with one of the k_guided_fast<TH> kernels (k_guided_wave is
+// tried first but every shape it takes is also taken here); if not, the exact-order path and its six float64 planes of
+// workspace are needed.
+bool guided_fast_handles(Shape s, int k)
+{
+    return fits(make_fast_geom(s, k, 8), 8) || fits(make_fast_geom(s, k, 4), 4) || fits(make_fast_geom(s, k, 2), 2);
+}
+
 // Returns UWIE_OK and sets *handled = 0 when the window is too wide for the LDS-resident formulation (the caller
 // then uses the exact-order path).
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
