@@ -58,6 +58,7 @@ SIGNATURES = {
     "uwie_create": [_I, ctypes.POINTER(_VP)],
     "uwie_destroy": [_VP],
     "uwie_profile_enable": [_VP, _I],
+    "uwie_profile_filter": [_VP, ctypes.c_char_p],
     "uwie_profile_collect": [_VP],
     "uwie_profile_row": [_VP, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_D), ctypes.POINTER(_I)],
     "uwie_params_init": [_PP, _I, _I],

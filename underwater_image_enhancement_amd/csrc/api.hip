@@ -270,6 +270,13 @@ int uwie_profile_enable(uwie_ctx *ctx, int on)
     return UWIE_OK;
 }
 
+int uwie_profile_filter(uwie_ctx *ctx, const char *kernel_name)
+{
+    UWIE_REQUIRE(ctx != nullptr, "ctx is NULL");
+    prof_filter(ctx->prof, kernel_name);
+    return UWIE_OK;
+}
+
 int uwie_profile_collect(uwie_ctx *ctx)
 {
     if (!ctx) {

@@ -55,6 +55,7 @@ struct Profiler;
 Profiler *prof_create();
 void prof_destroy(Profiler *p);
 void prof_enable(Profiler *p, bool on);
+void prof_filter(Profiler *p, const char *name);
 void prof_bind(Profiler *p);  // makes p the recorder of this host thread (nullptr / disabled = no recording)
 int prof_collect(Profiler *p);
 int prof_row(Profiler *p, int i, const char **name, double *ms, int *calls);

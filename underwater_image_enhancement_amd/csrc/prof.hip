@@ -10,6 +10,7 @@ namespace uwie {
 
 struct Profiler {
     bool on = false;
+    std::string only;  // when not empty: record launches of this kernel name only (two events per launch perturb the run)
     struct Rec {
         const char *name;
         hipEvent_t a, b;
@@ -43,6 +44,7 @@ ProfScope::ProfScope(const char *name, hipStream_t st) : rec_(-1), st_(st)
 {
     Profiler *p = g_current;
     if (!p) return;
+    if (!p->only.empty() && p->only != name) return;
     hipEvent_t a = p->take(), b = p->take();
     if (!a || !b) return;
     (void)hipEventRecord(a, st);
@@ -65,6 +67,8 @@ void prof_destroy(Profiler *p)
     for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
     delete p;
 }
+
+void prof_filter(Profiler *p, const char *name) { p->only = name ? name : ""; }
 
 void prof_enable(Profiler *p, bool on)
 {

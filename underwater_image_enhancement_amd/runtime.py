@@ -87,7 +87,10 @@ class Device:
         return int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
-    def profile(self, on: bool):
+    def profile(self, on: bool, only: str | None = None):
+        """Per-kernel HIP-event timing on/off; ``only`` restricts it to one kernel name (an event pair per launch costs
+        stream time, so a whole-job measurement records the one kernel it reports)."""
+        check(self.lib.uwie_profile_filter(self._ctx, only.encode() if only else None))
         check(self.lib.uwie_profile_enable(self._ctx, int(bool(on))))
 
     def profile_rows(self):
