@@ -162,6 +162,15 @@ def extras(dev, args, torch, _lib):
         ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 2)
         res[f"{dist}_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
         del fr
+    # opt-in: sub-batches on two streams (UWIE_STREAMS=2), whole-job rate on the headline workload
+    fr = synth_frames(args.dist, B, H, W, dev.torch_device, seed=1000 * 2)
+    os.environ["UWIE_STREAMS"] = "2"
+    try:
+        ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 3)
+    finally:
+        del os.environ["UWIE_STREAMS"]
+    res["two_streams_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
+    del fr
     # N1: the batch driver's fan-out, all six strategies per frame with shared cast detection / quadtree
     fan = synth_frames("underwater", min(B, 16), H, W, dev.torch_device, seed=1000 * 2)
     dev.enhance_all_u8(fan)

@@ -86,6 +86,10 @@ struct uwie_ctx {
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;
     uwie::Profiler *prof;
+    // two-way batch pipelining (uwie_enhance_u8): helper streams and the fork / join events, created on first use
+    hipStream_t aux[4];
+    hipEvent_t fork, join[4];
+    bool aux_ready;
 };
 
 namespace uwie {
