@@ -64,9 +64,11 @@ struct Elem {
     const float *xs;
     int W, kind;
     float mean[3];
-    __device__ __forceinline__ float get(const uint8_t *p, int c) const
+    __device__ __forceinline__ float get(const uint8_t *p, int c) const { return get(p, c, c); }
+    // value of byte p[i] taken as channel c
+    __device__ __forceinline__ float get(const uint8_t *p, int i, int c) const
     {
-        float v = px_norm_fast(p[c]);
+        float v = px_norm_fast(p[i]);
         if (px_atten(kind, c)) v = v * 0.85f;
         if (VAR) {
             const float d = v - mean[c];
@@ -131,6 +133,7 @@ __device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, f
 // The same for a full 128-element leaf, eight pixels per step: when the eight pixels lie in one row of the region
 // their 24 bytes come in as six (unaligned) dword loads instead of 24 byte loads.
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint4 __attribute__((aligned(1))) u128_unaligned;
 
 template <bool VAR>
 __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, float out[3])
@@ -138,6 +141,33 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
     int ly = e0 / r.cols, lx = e0 % r.cols;
     const uint8_t *p = el.img + ((size_t)(r.y0 + ly) * el.W + r.x0 + lx) * 3;
     float acc[3][8];
+    if (lx + 128 <= r.cols) {
+        // The leaf lies in one row: its 384 bytes come in as 24 (unaligned) 16-byte loads issued back to back; walking it
+        // 24 bytes at a time left one load round trip per step on the critical path (the kernel sat in s_waitcnt).
+        uint32_t raw[96];
+        const u128_unaligned *w = reinterpret_cast<const u128_unaligned *>(p);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const uint4 v = w[q];
+            raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int byte = 24 * it + 3 * j + c;
+                    const uint8_t u = (uint8_t)(raw[byte >> 2] >> (8 * (byte & 3)));
+                    const float v = el.get(&u, 0, c);
+                    acc[c][j] = it == 0 ? v : acc[c][j] + v;
+                }
+        }
+        out[0] = tree8(acc[0]);
+        out[1] = tree8(acc[1]);
+        out[2] = tree8(acc[2]);
+        return;
+    }
     for (int it = 0; it < 16; ++it) {
         uint8_t px[24];
         if (lx + 8 <= r.cols) {
