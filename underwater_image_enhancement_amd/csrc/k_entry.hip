@@ -25,9 +25,11 @@ constexpr int kRunPx = 256;      // pixels per lane inside a drilled chunk (64 *
 __global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ in, uint32_t *__restrict__ hist,
                                                     int npx, int nchunk)
 {
-    __shared__ uint32_t h[4][768];
-    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
-    for (int i = tid; i < 4 * 768; i += 256) (&h[0][0])[i] = 0;
+    // eight copies selected by lane & 7, rows padded by one word: neighbouring pixels mostly share their values, and equal
+    // values from different lanes of a wavefront would otherwise serialise on one LDS address (or one bank)
+    __shared__ uint32_t h[8][769];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, w = tid & 7;
+    for (int i = tid; i < 8 * 769; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const uint8_t *img = in + (size_t)b * npx * 3;
     const int p0 = c * kChunkPx, p1 = min(npx, p0 + kChunkPx);
@@ -45,7 +47,8 @@ __global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ 
     }
     __syncthreads();
     uint32_t *out = hist + ((size_t)b * nchunk + c) * 768;
-    for (int i = tid; i < 768; i += 256) out[i] = h[0][i] + h[1][i] + h[2][i] + h[3][i];
+    for (int i = tid; i < 768; i += 256)
+        out[i] = ((h[0][i] + h[1][i]) + (h[2][i] + h[3][i])) + ((h[4][i] + h[5][i]) + (h[6][i] + h[7][i]));
 }
 
 __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
