@@ -235,3 +235,30 @@ def torch_from(a):
     import torch
 
     return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
+    """UWIE_STREAMS=2/3 (sub-batches on internal streams, joined on the caller's stream) must not change a byte, for
+    every surface; the profiler's name filter records only the named kernel."""
+    from underwater_image_enhancement_amd import _lib
+
+    rng = np.random.default_rng(123)
+    frames = rng.integers(0, 256, (7, 66, 98, 3), dtype=np.uint8)
+    frames[2, :, :, 0] //= 3
+    want = {k: uw.enhance(frames, strategy=k) for k in (1, 3, 5)}
+    for n in ("2", "3"):
+        monkeypatch.setenv("UWIE_STREAMS", n)
+        for k, w in want.items():
+            assert np.array_equal(uw.enhance(frames, strategy=k), w), (n, k)
+    monkeypatch.delenv("UWIE_STREAMS")
+    dev = uw.get_device()
+    dev.profile(True)
+    uw.enhance(frames, strategy=2)
+    every = dev.profile_rows()
+    assert "k_guided_wave" in every and len(every) > 10
+    dev.profile(True, only="k_guided_wave")
+    uw.enhance(frames, strategy=2)
+    rows = dev.profile_rows()
+    dev.profile(False)
+    assert list(rows) == ["k_guided_wave"] and rows["k_guided_wave"][1] == 1
+    assert _lib.load().uwie_profile_filter(dev._ctx, None) == 0
