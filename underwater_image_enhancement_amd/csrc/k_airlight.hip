@@ -285,8 +285,10 @@ __global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ reg
 }
 
 // compute_Q's final arithmetic (six_stadigy.py:134-155) and the greedy step (six_stadigy.py:100-111).
-__global__ void k_q_select(Region *__restrict__ blk, const Region *__restrict__ regs, const float *__restrict__ tot,
-                           const float *__restrict__ vtot, const uint32_t *__restrict__ edges, int B, int level,
+// It also prepares the next level: the chosen block's quadrants (what k_make_quadrants would write) and zeroed edge
+// counters, so a level costs two launches fewer.
+__global__ void k_q_select(Region *__restrict__ blk, Region *__restrict__ regs, const float *__restrict__ tot,
+                           const float *__restrict__ vtot, uint32_t *__restrict__ edges, int B, int level, int min_size,
                            TraceRec *__restrict__ trace)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,7 +316,19 @@ __global__ void k_q_select(Region *__restrict__ blk, const Region *__restrict__ 
         t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
         for (int q = 0; q < 4; ++q) t.score[q] = score[q];
     }
-    blk[b] = regs[b * 4 + arg];
+    const Region k = regs[b * 4 + arg];
+    blk[b] = k;
+    const bool leaf = k.rows <= min_size || k.cols <= min_size;  // six_stadigy.py:76
+    const int mr = k.rows / 2, mc = k.cols / 2;                 // six_stadigy.py:85-86
+    Region q[4] = {{b, k.y0, k.x0, mr, mc},
+                   {b, k.y0, k.x0 + mc, mr, k.cols - mc},
+                   {b, k.y0 + mr, k.x0, k.rows - mr, mc},
+                   {b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc}};
+    for (int i = 0; i < 4; ++i) {
+        if (leaf) q[i].rows = q[i].cols = 0;
+        regs[b * 4 + i] = q[i];
+        edges[b * 4 + i] = 0;
+    }
 }
 
 // get_brightest_pixel (six_stadigy.py:160-165): argmax of (r+g)+b over the leaf, first maximum in raster order.
@@ -405,11 +419,12 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
     if (d_trace) UWIE_HIP_CHECK(hipMemsetAsync(d_trace, 0, (size_t)B * kMaxLevels * sizeof(TraceRec), st));
     const int maxChunks = max_chunks(s);
     int rmax = s.H, cmax = s.W;  // largest block any image can hold at this level
+    UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
+    UWIE_LAUNCH_CHECK();
+    UWIE_HIP_CHECK(hipMemsetAsync(L.edges, 0, sizeof(uint32_t) * nreg, st));
     for (int level = 0; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
         const int nch = cdiv((long long)qr * qc, kNpChunk);
-        UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
-        UWIE_LAUNCH_CHECK();
         UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum);
         UWIE_LAUNCH_CHECK();
@@ -422,10 +437,10 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
         UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, L.regs, L.csum, nreg,
                            maxChunks, L.vtot, L.mean);
         UWIE_LAUNCH_CHECK();
-        int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st);
+        int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
         if (rc != UWIE_OK) return rc;
         UWIE_LAUNCH(k_q_select, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, L.tot, L.vtot, L.edges, B,
-                           level, (TraceRec *)d_trace);
+                           level, min_size, (TraceRec *)d_trace);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
         cmax = qc;

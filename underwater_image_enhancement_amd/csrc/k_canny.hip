@@ -396,7 +396,7 @@ int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st)
 }
 
 int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
-                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st)
+                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed)
 {
     Carver c(ws);
     CannyBufs bufs = carve_canny(c, s);
@@ -408,7 +408,7 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
         return UWIE_E_INVALID;
     }
     const dim3 lgrid(cdiv(cdiv(bufs.tiles, kWalkTiles), 4), nreg);  // list walkers: 4 wavefronts per block
-    if (d_count) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
+    if (d_count && !count_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
     UWIE_LAUNCH(k_canny_gradnms, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
     UWIE_LAUNCH_CHECK();
