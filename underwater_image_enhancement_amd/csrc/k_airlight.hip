@@ -61,7 +61,6 @@ __global__ void k_make_quadrants(const Region *__restrict__ blk, Region *__restr
 template <bool VAR>
 struct Elem {
     const uint8_t *img;
-    const float *xs;
     int W, kind;
     float mean[3];
     __device__ __forceinline__ float get(const uint8_t *p, int c) const { return get(p, c, c); }
@@ -226,14 +225,10 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     if (c0 >= n) return;
     const int len = min(kNpChunk, n - c0);
 
-    __shared__ float xs[256];
     __shared__ PairwiseTree tree;
-    for (int i = lane; i < 256; i += 64) xs[i] = px_norm(i);
-    __syncthreads();
 
     Elem<VAR> el;
     el.img = in + (size_t)r.img * H * W * 3;
-    el.xs = xs;
     el.W = W;
     el.kind = kind ? kind[r.img] : 0;
     if (VAR) {
