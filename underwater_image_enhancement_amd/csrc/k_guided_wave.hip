@@ -394,7 +394,9 @@ int launch_wave(const uint8_t *d_gray, const float *d_t0, Shape s, double eps, d
     if (env) nbands = atoi(env);
     else {
         const long strips = (long)nstrips * s.B;
-        if (strips < 2L * resident) nbands = (int)cdiv((size_t)(2L * resident), (size_t)strips);
+        // ~12 wavefronts per resident slot evens out the tail (4K x 64, k = 15: 1 band 6.44 ms, 2: 6.01, 6: 5.89, 16: 6.22;
+        // every band pays 2(k-1) extra rows and a start-up sum)
+        if (strips < 12L * resident) nbands = (int)cdiv((size_t)(12L * resident), (size_t)strips);
     }
     nbands = max(1, min(nbands, s.H / max(64, 4 * K)));
     WaveGeom g;
