@@ -154,9 +154,18 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
     SelectPlan plan;
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
-    UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
-    UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
-    UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
+    // the restored image is clipped to [0, 1]: linear first digit, one collecting sweep (k_select.hip, select_lin_*);
+    // UWIE_SELECT_GENERIC=1 keeps the three-digit key sweeps
+    static const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    if (env_generic && atoi(env_generic) == 1) {
+        UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
+        UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
+    } else {
+        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st, true));
+        UWIE_TRY(select_lin_run(plan, P.F, s, st));
+    }
     if (k == 3) {
         UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));
         return launch_tail_plain(P.F, P.pct, 4, eps, 1, s, 0, 1.0, d_out_u8, d_out_f32, st);

@@ -200,7 +200,27 @@ struct SelectPlan {
     double t[kMaxPct];     // lerp weights (exactly representable values of the data's dtype)
     int nq;
     bool is64;
+    // linear-digit path (select_lin_*): per (image, channel) state, candidate lists and fallback flags
+    void *lin;
+    float *lists;          // [B*3][8][cap]
+    uint32_t *flags;       // [B*3] 1 = a candidate list overflowed, use the generic sweeps
+    uint32_t cap;
+    uint32_t ranks[2 * kMaxPct];
 };
+// Selection on clipped [0, 1] float32 planes with ONE sweep after the producer's histogram: the first digit is a linear
+// 2050-way split of [0, 1] (exact 0 and exact 1 get their own bins), which a whole frame spreads over thousands of bins,
+// so the elements of the few target bins are collected during the sweep and the rest of the selection runs on those
+// short lists.  lin_digit() is the split; the producer adds its counts to plan.ghist[(b*3+c)*kSelGroupStride + digit].
+constexpr int kLinBins = 2050;
+__host__ __device__ inline uint32_t lin_digit(float x)
+{
+    if (!(x > 0.0f)) return 0;          // zeros (and anything not above zero)
+    if (x >= 1.0f) return kLinBins - 1;
+    const uint32_t d = (uint32_t)(x * 2048.0f);  // exact product, truncation: monotone in x
+    return 1 + (d > 2047u ? 2047u : d);
+}
+int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipStream_t st);
 int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
 int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
@@ -217,7 +237,7 @@ int select_lerp64(const SelectPlan &plan, Shape s, double *d_out, hipStream_t st
 
 // k_fused.hip: the fused tail of the dehazing strategies
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
-                               float *d_planar, uint32_t *d_ghist, hipStream_t st);
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false);
 size_t tail_ws_bytes(Shape s, int tx, int ty);
 // d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,

@@ -22,15 +22,17 @@ __device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
 #define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-// grid (nblk, B), block 256
+// grid (nblk, B), block 256.  LIN: the histogram is over lin_digit() (select_lin_*), else over the top 11 key bits.
+template <bool LIN>
 __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                              const float *__restrict__ A, const double *__restrict__ t,
                                                              int npx, float *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist)
 {
-    __shared__ uint32_t h[3][2048];
+    constexpr int NB = LIN ? 2052 : 2048;
+    __shared__ uint32_t h[3][NB];
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < 3 * 2048; i += 256) (&h[0][0])[i] = 0;
+    for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const int k = kind ? kind[b] : 0;
     const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
@@ -71,9 +73,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
             r1[i] = clip01((float)((double)d1 / tv[i] + (double)a1));
             r2[i] = clip01((float)((double)d2 / tv[i] + (double)a2));
             if (i < n) {
-                bump(0, f32_key(r0[i]) >> 21);
-                bump(1, f32_key(r1[i]) >> 21);
-                bump(2, f32_key(r2[i]) >> 21);
+                bump(0, LIN ? lin_digit(r0[i]) : f32_key(r0[i]) >> 21);
+                bump(1, LIN ? lin_digit(r1[i]) : f32_key(r1[i]) >> 21);
+                bump(2, LIN ? lin_digit(r2[i]) : f32_key(r2[i]) >> 21);
             }
         }
         if (aligned && n == 4) {
@@ -92,9 +94,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
     for (int c = 0; c < 3; ++c)
         if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
     __syncthreads();
-    for (int i = tid; i < 3 * 2048; i += 256) {
+    for (int i = tid; i < 3 * NB; i += 256) {
         const uint32_t c = (&h[0][0])[i];
-        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / 2048) * kSelGroupStride + (i % 2048)], c);
+        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / NB) * kSelGroupStride + (i % NB)], c);
     }
 }
 
@@ -500,14 +502,18 @@ float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode ==
 }  // namespace
 
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
-                               float *d_planar, uint32_t *d_ghist, hipStream_t st)
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear)
 {
     int nblk = 2048 / s.B;
     nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
-    UWIE_LAUNCH(k_restore_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(), d_planar,
-                d_ghist);
+    if (linear)
+        UWIE_LAUNCH(k_restore_planar_hist<true>, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
+                    d_planar, d_ghist);
+    else
+        UWIE_LAUNCH(k_restore_planar_hist<false>, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
+                    d_planar, d_ghist);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

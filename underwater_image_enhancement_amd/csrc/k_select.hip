@@ -111,12 +111,14 @@ template <typename V>
 __global__ void __launch_bounds__(256) k_sel_hist(const V *__restrict__ vals, size_t img_stride, size_t chan_stride,
                                                   int elem_stride, int n,
                                                   const SelState<typename Traits<V>::K> *__restrict__ st, int shift,
-                                                  int bits, int first_pass, int ng_cap, uint32_t *__restrict__ ghist)
+                                                  int bits, int first_pass, int ng_cap, uint32_t *__restrict__ ghist,
+                                                  const uint32_t *__restrict__ only)
 {
     using K = typename Traits<V>::K;
     constexpr int VEC = 16 / sizeof(V);
     extern __shared__ uint32_t h[];
     const int bc = blockIdx.y, nbins = 1 << bits;
+    if (only && !only[bc]) return;  // fallback sweeps of the linear path: only planes whose candidate list overflowed
     const SelState<K> *s = st + bc;
     const int ng = first_pass ? 1 : min((int)s->ngroups, ng_cap);
     K gp[kMaxRanks];
@@ -167,12 +169,13 @@ __global__ void __launch_bounds__(256) k_sel_hist(const V *__restrict__ vals, si
 template <typename V>
 __global__ void __launch_bounds__(256) k_sel_scan(SelState<typename Traits<V>::K> *__restrict__ st,
                                                   const uint32_t *__restrict__ ghist, int bits, int nq, int last_pass,
-                                                  V *__restrict__ os)
+                                                  V *__restrict__ os, const uint32_t *__restrict__ only)
 {
     using K = typename Traits<V>::K;
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t found_digit, found_rank;
     const int bc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (only && !only[bc]) return;
     SelState<K> *s = st + bc;
     const int nbins = 1 << bits, per = nbins / 256;
     const uint32_t *gh = ghist + (size_t)bc * kMaxRanks * kBins;
@@ -331,7 +334,8 @@ __global__ void k_sel_init_stretch_ranks(SelState<uint32_t> *st, int nbc, const 
 }
 
 template <typename V>
-int run_t(const SelectPlan &plan, const V *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st)
+int run_t(const SelectPlan &plan, const V *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st,
+          const uint32_t *only = nullptr)
 {
     using K = typename Traits<V>::K;
     const long long n = (long long)s.npx();
@@ -349,11 +353,11 @@ int run_t(const SelectPlan &plan, const V *d_vals, int planar, Shape s, bool pas
             const size_t lds = (size_t)(p == 0 ? 1 : ng_cap) * (1u << bits) * sizeof(uint32_t);
             UWIE_LAUNCH(k_sel_hist<V>, dim3(blocks, nbc), dim3(256), lds, st, d_vals, (size_t)n * 3,
                         planar ? (size_t)n : (size_t)1, planar ? 1 : 3, (int)n, state, shift, bits, p == 0 ? 1 : 0, ng_cap,
-                        plan.ghist);
+                        plan.ghist, only);
             UWIE_LAUNCH_CHECK();
         }
         UWIE_LAUNCH(k_sel_scan<V>, dim3(nbc), dim3(256), 0, st, state, plan.ghist, bits, 2 * plan.nq,
-                    p == Traits<V>::NPASS - 1 ? 1 : 0, (V *)plan.os);
+                    p == Traits<V>::NPASS - 1 ? 1 : 0, (V *)plan.os, only);
         UWIE_LAUNCH_CHECK();
     }
     return UWIE_OK;
@@ -373,6 +377,277 @@ int lerp_t(const SelectPlan &plan, Shape s, V *d_out, hipStream_t st)
 
 }  // namespace
 
+// ===================================================================================== linear-digit selection
+namespace {
+
+struct LinState {              // one per (image, channel)
+    uint32_t rr[kMaxRanks];    // rank of the query inside its bin
+    uint32_t gid[kMaxRanks];   // group (distinct target bin) of the query; kLinDone: answered by the scan
+    uint32_t gbin[kMaxRanks];  // bin of the group
+    uint32_t gcount[kMaxRanks];  // elements collected for the group
+    uint32_t ngroups;
+};
+constexpr uint32_t kLinDone = 0xffffffffu;
+constexpr int kLinStage = 512;  // candidates a block stages in LDS per group before it reserves list space
+
+uint32_t lin_cap(Shape s) { return (uint32_t)std::max<size_t>(65536, s.npx() / 64); }
+
+// digit d (0 <= d < nbins, nbins <= 2304) with excl(d) <= rank < incl(d) over the LDS counts h[]; all 256 threads call
+__device__ void block_find_digit(const uint32_t *h, int nbins, uint32_t rank, uint32_t *wsum, uint32_t *found,
+                                 uint32_t &digit, uint32_t &rrank)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, per = (nbins + 255) / 256;
+    uint32_t loc = 0;
+    for (int i = 0; i < per; ++i) {
+        const int k = tid * per + i;
+        if (k < nbins) loc += h[k];
+    }
+    uint32_t incl = wave_incl_scan_u32(loc);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    if (tid == 0) { found[0] = (uint32_t)nbins - 1; found[1] = 0; }
+    __syncthreads();
+    for (int i = 0; i < w; ++i) incl += wsum[i];
+    const uint32_t excl = incl - loc;
+    if (excl <= rank && rank < incl) {
+        uint32_t acc = excl;
+        for (int i = 0; i < per; ++i) {
+            const int k = tid * per + i;
+            const uint32_t c = k < nbins ? h[k] : 0;
+            if (rank < acc + c) {
+                found[0] = (uint32_t)k;
+                found[1] = rank - acc;
+                break;
+            }
+            acc += c;
+        }
+    }
+    __syncthreads();
+    digit = found[0];
+    rrank = found[1];
+    __syncthreads();
+}
+
+// one block per (image, channel): the bin of every rank from the producer's histogram; ranks in the bins of exact
+// 0 / exact 1 are answered here
+__global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
+                                                  RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t h[kLinBins], wsum[4], found[2], qbin[kMaxRanks], qrr[kMaxRanks];
+    const int bc = blockIdx.x, tid = threadIdx.x;
+    const uint32_t *gh = ghist + (size_t)bc * kSelGroupStride;
+    for (int i = tid; i < kLinBins; i += 256) h[i] = gh[i];
+    __syncthreads();
+    for (int q = 0; q < ranks.n; ++q) {
+        uint32_t d, rr;
+        block_find_digit(h, kLinBins, ranks.r[q], wsum, found, d, rr);
+        if (tid == 0) { qbin[q] = d; qrr[q] = rr; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        LinState s;
+        uint32_t ng = 0;
+        for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; s.gcount[q] = 0; }
+        for (int q = 0; q < ranks.n; ++q) {
+            s.rr[q] = qrr[q];
+            if (qbin[q] == 0 || qbin[q] == kLinBins - 1) {  // every element of these bins is 0 resp. 1
+                os[bc * kMaxRanks + q] = qbin[q] == 0 ? 0.0f : 1.0f;
+                continue;
+            }
+            uint32_t g = 0;
+            for (; g < ng; ++g)
+                if (s.gbin[g] == qbin[q]) break;
+            if (g == ng) s.gbin[ng++] = qbin[q];
+            s.gid[q] = g;
+        }
+        s.ngroups = ng;
+        st[bc] = s;
+        flags[bc] = 0;
+    }
+}
+
+// grid (blocks, B*3): one sweep over the plane; elements whose bin is a target bin go to that group's list.  A block
+// stages its candidates in LDS (they are ~0.5 % of the elements) and reserves list space for a batch at a time.
+__global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ vals, int n, LinState *__restrict__ st,
+                                                     float *__restrict__ lists, uint32_t cap)
+{
+    __shared__ float stg[kMaxRanks][kLinStage];
+    __shared__ uint32_t scount[kMaxRanks], sbase[kMaxRanks];
+    const int bc = blockIdx.y, tid = threadIdx.x;
+    LinState *s = st + bc;
+    const int ng = (int)s->ngroups;
+    if (ng == 0) return;
+    // Target bins are interior (1..2048: the scan answers bins 0 and 2049 itself), so with d = (uint32)(x * 2048):
+    // x is in bin tb  <=>  d == tb - 1, except that x = 0 also gives d = 0: zeros are mapped to a d nobody asks for.
+    uint32_t gd[kMaxRanks];
+#pragma unroll
+    for (int g = 0; g < kMaxRanks; ++g) gd[g] = g < ng ? s->gbin[g] - 1 : kLinDone;
+    if (tid < kMaxRanks) scount[tid] = 0;
+    __syncthreads();
+    float *L = lists + (size_t)bc * kMaxRanks * cap;
+    const float *v = vals + (size_t)bc * n;
+    const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
+    const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    auto take = [&](float x, bool live) {
+        const uint32_t d = (live && x > 0.0f) ? (uint32_t)(x * 2048.0f) : 0xfffffffeu;
+        uint32_t idx = kLinDone;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) idx = d == gd[g] ? (uint32_t)g : idx;
+        if (ng > 4) {
+#pragma unroll
+            for (int g = 4; g < kMaxRanks; ++g) idx = d == gd[g] ? (uint32_t)g : idx;
+        }
+        if (idx != kLinDone) {
+            const uint32_t pos = atomicAdd(&scount[idx], 1u);
+            if (pos < (uint32_t)kLinStage) stg[idx][pos] = x;  // (a fuller stage is caught by flush(): the plane falls back)
+        }
+    };
+    // all threads of the block call: move the staged candidates to the lists when a stage is three quarters full
+    auto flush = [&](bool force) {
+        __syncthreads();
+        bool need = force;
+        for (int g = 0; g < ng; ++g) need = need || scount[g] > (uint32_t)(kLinStage * 3 / 4);
+        if (!need) return;  // block-uniform
+        if (tid < ng) {
+            const uint32_t c = scount[tid];
+            // a stage that overflowed lost elements: make the list look overfull so that the plane takes the generic path
+            sbase[tid] = atomicAdd(&s->gcount[tid], c > (uint32_t)kLinStage ? cap + 1 : c);
+        }
+        __syncthreads();
+        for (int g = 0; g < ng; ++g) {
+            const uint32_t c = min(scount[g], (uint32_t)kLinStage), base = sbase[g];
+            for (uint32_t i = tid; i < c; i += 256)
+                if (base + i < cap) L[(size_t)g * cap + base + i] = stg[g][i];
+        }
+        __syncthreads();
+        if (tid < kMaxRanks) scount[tid] = 0;
+        __syncthreads();
+    };
+    const bool vec = ((size_t)v & 15) == 0;
+    const int hiv = vec ? lo + ((hi - lo) / 4) * 4 : lo;
+    constexpr int U = 4;
+    for (int base = lo; base < hiv; base += U * 1024) {  // block-uniform trip count
+        const int i = base + tid * 4;
+        float4 raw[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = i + u * 1024 < hiv;
+            raw[u] = ok[u] ? *reinterpret_cast<const float4 *>(v + i + u * 1024) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            take(raw[u].x, ok[u]); take(raw[u].y, ok[u]); take(raw[u].z, ok[u]); take(raw[u].w, ok[u]);
+        }
+        flush(false);
+    }
+    for (int t0 = hiv; t0 < hi; t0 += 256) {
+        const int j = t0 + tid;
+        take(j < hi ? v[j] : 0.0f, j < hi);
+        flush(false);
+    }
+    flush(true);
+}
+
+// one block per (image, channel, query): the query is finished on its group's list by a 3-digit radix select
+__global__ void __launch_bounds__(256) k_lin_finish(const LinState *__restrict__ st, const float *__restrict__ lists,
+                                                    uint32_t cap, float *__restrict__ os, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t h[2048], wsum[4], found[2];
+    const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;  // grid (B*3, ranks)
+    const LinState *s = st + bc;
+    const uint32_t g = s->gid[q];
+    if (g == kLinDone) return;  // block-uniform: answered by the scan
+    const uint32_t cnt = s->gcount[g];
+    if (cnt > cap) {
+        if (tid == 0) flags[bc] = 1;
+        return;
+    }
+    const float *L = lists + ((size_t)bc * kMaxRanks + g) * cap;
+    uint32_t prefix = 0, r = s->rr[q];
+    for (int p = 0; p < 3; ++p) {
+        const int shift = Traits<float>::shift(p), bits = Traits<float>::bits(p), nbins = 1 << bits;
+        for (int i = tid; i < nbins; i += 256) h[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const uint32_t key = f32_key(L[i]);
+            if (p == 0 || (key >> (shift + bits)) == prefix) atomicAdd(&h[(key >> shift) & (nbins - 1)], 1u);
+        }
+        __syncthreads();
+        uint32_t d, rr;
+        block_find_digit(h, nbins, r, wsum, found, d, rr);
+        prefix = (prefix << bits) | d;
+        r = rr;
+    }
+    if (tid == 0) os[bc * kMaxRanks + q] = Traits<float>::value(prefix);
+}
+
+struct LinBufs {
+    LinState *lin;
+    float *lists;
+    uint32_t *flags;
+};
+LinBufs carve_lin(Carver &c, Shape s)
+{
+    LinBufs b;
+    const size_t nbc = (size_t)s.B * 3;
+    b.lin = c.take<LinState>(nbc);
+    b.flags = c.take<uint32_t>(nbc);
+    b.lists = c.take<float>(nbc * kMaxRanks * lin_cap(s));
+    return b;
+}
+
+}  // namespace
+
+int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan)
+{
+    UWIE_REQUIRE(nq >= 1 && nq <= kMaxPct, "percentiles: 1..4 percentiles per call");
+    const long long n = (long long)s.npx();
+    UWIE_REQUIRE(n >= 1 && n < (1ll << 31), "percentiles: plane size out of range");
+    Carver c(ws);
+    const int nbc = s.B * 3;
+    plan->state = c.take<SelState<uint64_t>>(nbc);
+    plan->ghist = c.take<uint32_t>((size_t)nbc * kMaxRanks * kBins);
+    plan->os = c.take<double>((size_t)nbc * kMaxRanks);
+    const LinBufs lb = carve_lin(c, s);
+    plan->lin = lb.lin;
+    plan->lists = lb.lists;
+    plan->flags = lb.flags;
+    plan->cap = lin_cap(s);
+    plan->nq = nq;
+    plan->is64 = false;
+    for (int j = 0; j < nq; ++j)
+        percentile_indices<float>(n, q_percent[j], &plan->ranks[2 * j], &plan->ranks[2 * j + 1], &plan->t[j]);
+    // only the first kLinBins counters of every (image, channel) are used by the producer
+    UWIE_HIP_CHECK(hipMemsetAsync(plan->ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    return UWIE_OK;
+}
+
+// After the producer has filled the linear-digit histogram: scan -> one collecting sweep -> finish on the lists;
+// planes whose list overflowed (a heavy bin, e.g. a constant image) take the generic three sweeps.
+int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipStream_t st)
+{
+    const int n = (int)s.npx(), nbc = s.B * 3;
+    RankList ranks;
+    ranks.n = 2 * plan.nq;
+    for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
+    LinState *lin = (LinState *)plan.lin;
+    UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags);
+    UWIE_LAUNCH_CHECK();
+    int blocks = (int)(((long long)n + 262143) / 262144);
+    if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
+    blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_lin_finish, dim3(nbc, ranks.n), dim3(256), 0, st, lin, plan.lists, plan.cap, (float *)plan.os, plan.flags);
+    UWIE_LAUNCH_CHECK();
+    // generic path for the flagged planes (its kernels return at once for the others)
+    UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
+    UWIE_LAUNCH_CHECK();
+    UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    return run_t<float>(plan, d_planar, 1, s, false, st, plan.flags);
+}
+
 size_t select_ws_bytes(Shape s)
 {
     Carver c(nullptr);
@@ -380,6 +655,7 @@ size_t select_ws_bytes(Shape s)
     c.take<SelState<uint64_t>>(nbc);
     c.take<uint32_t>(nbc * kMaxRanks * kBins);
     c.take<double>(nbc * kMaxRanks);
+    carve_lin(c, s);
     return c.total();
 }
 
