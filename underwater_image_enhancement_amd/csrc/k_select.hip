@@ -11,6 +11,7 @@
 // (4 percentiles) per channel are resolved in the same sweeps; queries sharing a prefix share a histogram ("group").
 // A producer kernel may accumulate the first digit's histogram itself (k_fused.hip), saving one sweep.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "devutil.h"
@@ -390,7 +391,14 @@ struct LinState {              // one per (image, channel)
 constexpr uint32_t kLinDone = 0xffffffffu;
 constexpr int kLinStage = 512;  // candidates a block stages in LDS per group before it reserves list space
 
-uint32_t lin_cap(Shape s) { return (uint32_t)std::max<size_t>(65536, s.npx() / 64); }
+// list capacity per (image, channel, group); UWIE_LIN_CAP overrides it (tests force the overflow / fallback path)
+uint32_t lin_cap(Shape s)
+{
+    const uint32_t dflt = (uint32_t)std::max<size_t>(65536, s.npx() / 64);
+    const char *env = getenv("UWIE_LIN_CAP");
+    const long v = env ? atol(env) : 0;
+    return v > 0 && v < (long)dflt ? (uint32_t)v : dflt;
+}
 
 // digit d (0 <= d < nbins, nbins <= 2304) with excl(d) <= rank < incl(d) over the LDS counts h[]; all 256 threads call
 __device__ void block_find_digit(const uint32_t *h, int nbins, uint32_t rank, uint32_t *wsum, uint32_t *found,
