@@ -14,8 +14,10 @@
 //                  (tile, wavefront) into that wavefront's own list slot: no atomics, no second barrier.
 //   k_canny_union  8-connected components of the candidates: lock-free union-find on pixel indices (links always point
 //                  to the smaller index; agent-scope atomics, so XCD placement is irrelevant)
-//   k_canny_mark   pointer jumping: every candidate points at its root; roots that own a strong pixel are flagged
-//   k_canny_emit   a candidate is an edge iff its root is flagged (= hysteresis); per-region edge counts, edge map
+//   k_canny_mark   walks the tile-local ROOTS only (k_canny_gradnms records each with its component's size and number of
+//                  strong pixels): the global root of a part that owns a strong pixel is flagged
+//   k_canny_emit   per-region edge counts = sizes of the parts whose global root is flagged (= hysteresis)
+//   k_canny_paint  the edge map (standalone cv2.Canny only): candidates whose global root is flagged
 // The component kernels walk the candidate lists (one wavefront per tile), not the frame: smooth frames have few
 // candidates.
 // Hysteresis is order independent (an edge pixel is a weak-or-strong pixel whose 8-connected component holds a
@@ -33,6 +35,8 @@ struct CannyBufs {
     uint8_t *flag;     // root owns a strong pixel, candidates only
     uint32_t *cand;    // candidate lists: 512 entries per (tile, wavefront), pixel index inside the frame
     uint32_t *ncand;   // their lengths, [tile][4]
+    uint2 *roots;      // tile-local component roots, same slots: {pixel index of the root, size | strong pixels << 16}
+    uint32_t *nroot;   // their counts, [tile][4]
     int tiles;         // tiles per region in this launch
 };
 
@@ -88,14 +92,16 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
                                                        int H, int W, int tiles_x, int low, int high, CannyBufs bufs)
 {
     __shared__ __attribute__((aligned(8))) uint8_t sg[kSG_H][kSG_W];
-    __shared__ uint32_t s_lab[kCT_H * kCT_W];
+    __shared__ uint32_t s_lab[kCT_H * kCT_W], s_info[kCT_H * kCT_W];
     __shared__ uint8_t s_keep[256];
+    __shared__ uint32_t s_total;  // candidates in the tile
     const Region r = regs[blockIdx.y];
     const int ty0 = (blockIdx.x / tiles_x) * kCT_H, tx0 = (blockIdx.x % tiles_x) * kCT_W;  // tile origin inside the region
     const int tid = threadIdx.x;
+    if (tid == 0) s_total = 0;  // (the barrier after the tile fill orders this before the atomics)
     const size_t sub = ((size_t)blockIdx.y * bufs.tiles + blockIdx.x) * 4 + (tid >> 6);  // this wavefront's list
     if (ty0 >= r.rows || tx0 >= r.cols) {
-        if ((tid & 63) == 0) bufs.ncand[sub] = 0;
+        if ((tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = 0;
         return;
     }
     const size_t base = (size_t)r.img * H * W;
@@ -198,10 +204,12 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
     // ---- tile-local components in LDS: on dense maps (noise inputs) nearly every pixel is a candidate and a union-find
     // over global memory alone is contention-bound; merging inside the tile first leaves only the tile-border links to it
+    if (ncand) atomicAdd(&s_total, ncand);
     s_keep[tid] = (uint8_t)keepmask;  // 4x2 candidate bits of this thread's block
     for (uint32_t km = keepmask; km; km &= km - 1) {
         const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
         s_lab[li] = li;
+        s_info[li] = 0;
     }
     __syncthreads();
     auto is_cand = [&](int ly, int lx) -> bool {  // tile coordinates, inside the tile
@@ -217,20 +225,63 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
         }
     }
     __syncthreads();
-    // candidate list of this (tile, wavefront): fixed slot, so no atomics and nothing to wait for; every candidate's
-    // global label starts at the root of its tile-local component
-    const uint32_t incl = wave_incl_scan_u32(ncand);
-    if ((tid & 63) == 63) bufs.ncand[sub] = incl;
-    if (ncand) {
-        uint32_t *dst = bufs.cand + sub * 512 + (incl - ncand);
-        for (uint32_t km = keepmask; km; km &= km - 1) {
+    // Dense tiles: size and number of strong pixels of every tile-local component are gathered at its root, and only the
+    // roots are recorded for the hysteresis walk.  Sparse tiles skip that (one more barrier, an LDS atomic per
+    // candidate): every candidate is recorded as a part of size one.
+    const bool dense = s_total > 256;  // block-uniform
+    uint32_t myroot[8];
+    {
+        int k = 0;
+        for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
-            const int root = lds_find(s_lab, li);
+            const uint32_t root = (uint32_t)lds_find(s_lab, li);
+            myroot[k] = root;
+            if (dense) {
+                const bool strong = ((cls[b >> 2] >> (8 * (b & 3))) & 0xffu) == 2u;
+                atomicAdd(&s_info[root], 1u | (strong ? 0x10000u : 0u));
+            }
+        }
+    }
+    if (dense) __syncthreads();
+    // Lists of this (tile, wavefront), fixed slots (no atomics, nothing to wait for): every candidate, with its global
+    // label starting at the root of its tile-local component, and the roots with their component's size / strength.
+    // Hysteresis then only has to look at roots: a component is an edge component iff some root of it is strong.
+    uint32_t nr = 0;
+    {
+        int k = 0;
+        for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
+            const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
+            nr += !dense || (int)myroot[k] == li;
+        }
+    }
+    const uint32_t both = wave_incl_scan_u32(ncand | (nr << 16));  // one scan for both list offsets (<= 512 each)
+    const uint32_t incl = both & 0xffffu, rincl = both >> 16;
+    if ((tid & 63) == 63) {
+        bufs.ncand[sub] = incl;
+        bufs.nroot[sub] = rincl;
+    }
+    {
+        uint32_t *dst = bufs.cand + sub * 512 + (incl - ncand);
+        int k = 0;
+        for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
+            const int b = __ffs(km) - 1;
+            const int root = (int)myroot[k];
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
             const int proot = (r.y0 + ty0 + root / kCT_W) * W + r.x0 + tx0 + root % kCT_W;
             bufs.label[base + p] = proot;
-            bufs.flag[base + p] = 0;
             *dst++ = (uint32_t)p;
+        }
+    }
+    if (nr) {
+        uint2 *dst = bufs.roots + sub * 512 + (rincl - nr);
+        int k = 0;
+        for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
+            const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
+            if (dense && (int)myroot[k] != li) continue;
+            const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
+            const bool strong = ((cls[b >> 2] >> (8 * (b & 3))) & 0xffu) == 2u;
+            bufs.flag[base + p] = 0;
+            *dst++ = make_uint2((uint32_t)p, dense ? s_info[li] : (1u | (strong ? 0x10000u : 0u)));
         }
     }
 }
@@ -272,14 +323,14 @@ __device__ void uf_union(int32_t *L, int a, int b)
 constexpr int kWalkTiles = 16;
 
 template <class F>
-__device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
+__device__ __forceinline__ void for_list(const uint32_t *__restrict__ counts, int tiles, F f)
 {
     const int lane = threadIdx.x & 63;
     const int tile0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kWalkTiles;
-    if (tile0 >= bufs.tiles) return;  // wavefront-uniform
-    const size_t sub0 = ((size_t)blockIdx.y * bufs.tiles + tile0) * 4;
-    const int nsub = min(64, (bufs.tiles - tile0) * 4);
-    const uint32_t cnt = lane < nsub ? bufs.ncand[sub0 + lane] : 0;
+    if (tile0 >= tiles) return;  // wavefront-uniform
+    const size_t sub0 = ((size_t)blockIdx.y * tiles + tile0) * 4;
+    const int nsub = min(64, (tiles - tile0) * 4);
+    const uint32_t cnt = lane < nsub ? counts[sub0 + lane] : 0;
     const uint32_t incl = wave_incl_scan_u32(cnt), excl = incl - cnt, total = __shfl(incl, 63);
     for (uint32_t b0 = 0; b0 < total; b0 += 64) {
         const uint32_t idx = b0 + lane;
@@ -290,8 +341,13 @@ __device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
             if (e <= idx) sl += step;
         }
         const uint32_t off = idx - __shfl(excl, sl);
-        if (idx < total) f((int)bufs.cand[(sub0 + sl) * 512 + off]);
+        if (idx < total) f((sub0 + sl) * 512 + off);  // position in the list array
     }
+}
+template <class F>
+__device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
+{
+    for_list(bufs.ncand, bufs.tiles, [&](size_t pos) { f((int)bufs.cand[pos]); });
 }
 
 __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
@@ -315,12 +371,14 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
     });
 }
 
-// every candidate points at its root; roots that own a strong pixel are flagged
+// a component is an edge component iff one of its tile-local parts owns a strong pixel: flag its global root
 __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     const size_t base = (size_t)regs[blockIdx.y].img * H * W;
     int32_t *L = bufs.label + base;
-    for_candidates(bufs, [&](int p) {
+    for_list(bufs.nroot, bufs.tiles, [&](size_t pos) {
+        const uint2 e = bufs.roots[pos];
+        const int p = (int)e.x;
         int root = p;
         for (;;) {
             const int q = ld_label(L, root);
@@ -328,28 +386,38 @@ __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ r
             root = q;
         }
         if (root != p) atomicMin(L + p, root);
-        if (bufs.cmap[base + p] == 2) bufs.flag[base + root] = 1;
+        if (e.y >> 16) bufs.flag[base + root] = 1;
     });
 }
 
+// per-region edge counts: the sizes of the tile-local parts whose global root is flagged (= hysteresis)
 __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
-                                                    uint32_t *__restrict__ count, uint8_t *__restrict__ edges)
+                                                    uint32_t *__restrict__ count)
 {
     const size_t base = (size_t)regs[blockIdx.y].img * H * W;
     const int32_t *L = bufs.label + base;
     uint32_t mine = 0;
+    for_list(bufs.nroot, bufs.tiles, [&](size_t pos) {
+        const uint2 e = bufs.roots[pos];
+        int root = (int)e.x;
+        while (L[root] != root) root = L[root];
+        if (bufs.flag[base + root]) mine += e.y & 0xffffu;
+    });
+    const uint32_t tot = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + blockIdx.y, tot);
+}
+
+// the edge map itself (standalone cv2.Canny): every candidate whose component is flagged
+__global__ void __launch_bounds__(256) k_canny_paint(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
+                                                     uint8_t *__restrict__ edges)
+{
+    const size_t base = (size_t)regs[blockIdx.y].img * H * W;
+    const int32_t *L = bufs.label + base;
     for_candidates(bufs, [&](int p) {
         int root = p;
         while (L[root] != root) root = L[root];
-        if (bufs.flag[base + root]) {
-            ++mine;
-            if (edges) edges[base + p] = 255;
-        }
+        if (bufs.flag[base + root]) edges[base + p] = 255;
     });
-    if (count) {
-        const uint32_t tot = wave_sum_u32(mine);
-        if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + blockIdx.y, tot);
-    }
 }
 
 __global__ void k_full_regions(Region *regs, int B, int H, int W)
@@ -376,6 +444,8 @@ CannyBufs carve_canny(Carver &c, Shape s)
     b.tiles = 0;  // set per launch
     b.cand = c.take<uint32_t>(canny_list_tiles(s) * 2048);
     b.ncand = c.take<uint32_t>(canny_list_tiles(s) * 4);
+    b.roots = c.take<uint2>(canny_list_tiles(s) * 2048);
+    b.nroot = c.take<uint32_t>(canny_list_tiles(s) * 4);
     return b;
 }
 
@@ -416,8 +486,14 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_canny_mark, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_canny_emit, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_count, d_edges);
-    UWIE_LAUNCH_CHECK();
+    if (d_count) {
+        UWIE_LAUNCH(k_canny_emit, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_count);
+        UWIE_LAUNCH_CHECK();
+    }
+    if (d_edges) {
+        UWIE_LAUNCH(k_canny_paint, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_edges);
+        UWIE_LAUNCH_CHECK();
+    }
     return UWIE_OK;
 }
 
