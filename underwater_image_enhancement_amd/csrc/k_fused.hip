@@ -8,6 +8,8 @@
 //                          -> (y*255).astype(u8) (S6:430); everything after LAB2RGB is a 256-entry LUT per launch
 //   k_stretch_out          the CLAHE-free tail (strategy 3): stretch -> white_balance -> output
 // Arithmetic is the same as in the unfused stage kernels (k_tail.hip, k_clahe.hip), operation for operation.
+#include <cstdlib>
+
 #include "common.h"
 #include "devutil.h"
 
@@ -504,8 +506,11 @@ float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode ==
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                                float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear)
 {
-    int nblk = 2048 / s.B;
-    nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
+    // 24.6 KB of LDS per block: six blocks per CU, 1536 resident on the chip.  Enough blocks for several full rounds
+    // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
+    static const char *env_nb = getenv("UWIE_RESTORE_BLOCKS");
+    int nblk = env_nb ? atoi(env_nb) : cdiv(12288, s.B);  // 4K x 64: 32 per frame 2.79 ms, 96: 2.52, 192: 2.43, 384: 2.47
+    nblk = nblk < 16 ? 16 : nblk > 1024 ? 1024 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     if (linear)
@@ -561,7 +566,8 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     UWIE_LAUNCH_CHECK();
     // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
     const int cells = (tx + 1) * (ty + 1);
-    int nchunk = cdiv(8192, cells * s.B);
+    static const char *env_nc = getenv("UWIE_CLAHE_CHUNKS");
+    int nchunk = env_nc ? atoi(env_nc) : cdiv(25920, cells * s.B);  // ~12 rounds of the 2048 resident blocks
     nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
     UWIE_LAUNCH(k_clahe_apply_out, dim3(cells * nchunk, s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g, nchunk, gamma_mode,
                 gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);

@@ -642,7 +642,8 @@ int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipSt
     LinState *lin = (LinState *)plan.lin;
     UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags);
     UWIE_LAUNCH_CHECK();
-    int blocks = (int)(((long long)n + 262143) / 262144);
+    static const char *env_cb = getenv("UWIE_COLLECT_BLOCKS");
+    int blocks = env_cb ? atoi(env_cb) : (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
     UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
