@@ -267,22 +267,29 @@ def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
 def test_select_paths_agree(uw, orc, monkeypatch):
     """The percentile selection of strategies 1-3 has three routes: linear first digit with collected candidates (default),
     its fallback to the generic sweeps when a candidate list overflows (forced here with a tiny list capacity, and hit for
-    real by a nearly constant frame), and the generic three-digit sweeps alone.  All must give the oracle's bytes."""
+    real by a nearly constant frame), and the generic three-digit sweeps alone; strategies 1-2 run them either on the
+    stored planes (default) or on the restored image recomputed per sweep (UWIE_RESTORE_RECOMPUTE=1).  All must give the
+    oracle's bytes."""
     rng = np.random.default_rng(404)
     noisy = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
     flatish = np.empty((330, 310, 3), np.uint8)  # > 65536 pixels, almost all of one colour: one heavy interior bin
     flatish[:] = (90, 140, 180)
     flatish[::7, ::5] = rng.integers(0, 256, flatish[::7, ::5].shape, dtype=np.uint8)
-    for name, u8 in (("noisy", noisy), ("flatish", flatish)):
-        for k in (1, 2, 3):
-            want = orc.enhance_u8(u8, k)
-            check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}")
-            monkeypatch.setenv("UWIE_LIN_CAP", "16")
-            check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}")
-            monkeypatch.delenv("UWIE_LIN_CAP")
+    odd = rng.integers(0, 256, (131, 203, 3), dtype=np.uint8)  # pixel count and tile widths not multiples of 4
     big = np.empty((700, 720, 3), np.uint8)  # a block meets > 512 candidates of one bin in one step: LDS stage overflow
     big[:] = (60, 120, 200)
     big[::11, ::13] = rng.integers(0, 256, big[::11, ::13].shape, dtype=np.uint8)
-    check_u8(uw.enhance(big, strategy=2), orc.enhance_u8(big, 2), "stage overflow, strategy 2 on big flat frame")
+    want_big = orc.enhance_u8(big, 2)
+    for store in ("0", "1"):
+        monkeypatch.setenv("UWIE_RESTORE_RECOMPUTE", store)
+        for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd)):
+            for k in (1, 2, 3):
+                want = orc.enhance_u8(u8, k)
+                check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}, recompute={store}")
+                monkeypatch.setenv("UWIE_LIN_CAP", "16")
+                check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, recompute={store}")
+                monkeypatch.delenv("UWIE_LIN_CAP")
+        check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, recompute={store}")
+    monkeypatch.delenv("UWIE_RESTORE_RECOMPUTE")
     batch = np.stack([noisy[:120, :200], flatish[:120, :200], noisy[30:150, 10:210]])
     assert np.array_equal(uw.enhance(batch, strategy=2), np.stack([uw.enhance(f, strategy=2) for f in batch]))

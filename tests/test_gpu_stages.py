@@ -230,6 +230,32 @@ def test_restore_matches_reference(dev, golden, tag):
     same(got[0].cpu().numpy(), golden[f"{tag}/s6_restore"])
 
 
+def test_restore_shared_reciprocal_is_the_division(dev):
+    """restore.h evaluates the three float64 quotients of a pixel with one reciprocal (the division's own Newton /
+    Markstein sequence, shared).  Against NumPy's IEEE division on 6 M random (byte, A, t) triples: every float32 equal,
+    t over the clip range [0.1, 1] with full mantissas, over ten decades, and outside the fast range (true division)."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    B, H, W = 4, 512, 1024
+    u8 = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    A = rng.random((B, 3)).astype(np.float32)
+    t = rng.uniform(0.1, 1.0, (B, H, W))
+    t[1] = np.exp(rng.uniform(np.log(1e-5), np.log(1e5), (H, W)))
+    t[2, ::2] = np.ldexp(rng.uniform(0.5, 1.0, t[2, ::2].shape), rng.integers(-140, -101, t[2, ::2].shape))
+    t[2, 1::4] = np.ldexp(rng.uniform(0.5, 1.0, t[2, 1::4].shape), rng.integers(102, 140, t[2, 1::4].shape))
+    t[3, :, ::3] = 1.0 - np.ldexp(1.0, -53)  # all-ones mantissa: the reciprocal's hard case
+    kinds = np.array([0, 1, 2, 0], np.int32)
+    got = dev.restore(dev.tensor(u8), dev.tensor(A), dev.tensor(t), torch.tensor(kinds, device=dev.torch_device)).cpu().numpy()
+    x = u8.astype(np.float32) / np.float32(255.0)
+    for b in range(B):
+        if kinds[b]:
+            x[b, :, :, kinds[b]] = x[b, :, :, kinds[b]] * np.float32(0.85)
+    d = x - A[:, None, None, :]
+    want = np.clip((d.astype(np.float64) / t[..., None] + A[:, None, None, :].astype(np.float64)).astype(np.float32), 0, 1)
+    assert got.dtype == np.float32 and np.array_equal(got, want), int((got != want).sum())
+
+
 # ------------------------------------------------------------------ percentiles / stretch / gamma / clahe on float images
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
 def test_percentiles_and_stretch_match_reference(dev, golden, tag):

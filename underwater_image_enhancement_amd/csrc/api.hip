@@ -157,14 +157,22 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     // the restored image is clipped to [0, 1]: linear first digit, one collecting sweep (k_select.hip, select_lin_*);
     // UWIE_SELECT_GENERIC=1 keeps the three-digit key sweeps
     static const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    const RestoreSrc src{d_in, kind, P.A, P.t};
+    bool recompute = false;
     if (env_generic && atoi(env_generic) == 1) {
         UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
         UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
     } else {
+        // UWIE_RESTORE_RECOMPUTE=1 (strategies 1 and 2): the restored image is never stored, the histogram sweep, the
+        // collecting sweep and the stretch each recompute it from the frame and t (restore.h; 36 instead of 50 bytes
+        // per pixel over the three).  Measured slower at 4K x 64 (5.7 vs 5.4 ms for the three: ~90 VALU operations per
+        // pixel and sweep meet the HBM time of 11 B/px), so it is opt-in: it is the mode for a tight workspace.
+        const char *env_rc = getenv("UWIE_RESTORE_RECOMPUTE");  // read per call: the tests compare both modes
+        recompute = k != 3 && env_rc && atoi(env_rc) == 1;
         UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st, true));
-        UWIE_TRY(select_lin_run(plan, P.F, s, st));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true));
+        UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
     }
     if (k == 3) {
         UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));
@@ -172,7 +180,7 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     }
     UWIE_TRY(select_lerp(plan, s, P.pct, st));
     return launch_tail_clahe(ctx, P.F, P.pct, 2, eps, 0, s, p->clip_limit, p->tiles_x, p->tiles_y, k == 1 ? 1 : 0,
-                             p->gamma, d_out_u8, d_out_f32, P.scratch, st);
+                             p->gamma, d_out_u8, d_out_f32, P.scratch, st, recompute ? &src : nullptr);
 }
 
 // Writes the strategy's float image to d_out_f32 and/or its (y*255).astype(u8) image to d_out_u8.

@@ -220,7 +220,10 @@ __host__ __device__ inline uint32_t lin_digit(float x)
     return 1 + (d > 2047u ? 2047u : d);
 }
 int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
-int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipStream_t st);
+struct RestoreSrc;
+// src != nullptr: the values are recomputed from *src; d_planar is then only written (and read back) for planes that
+// fall back to the generic sweeps
+int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc *src = nullptr);
 int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
 int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
@@ -236,13 +239,21 @@ int select_run64(const SelectPlan &plan, const double *d_vals, int planar, Shape
 int select_lerp64(const SelectPlan &plan, Shape s, double *d_out, hipStream_t st);
 
 // k_fused.hip: the fused tail of the dehazing strategies
+// what the restored image (six_stadigy.py:183-188) is made of; consumers may recompute it from here (restore.h)
+struct RestoreSrc {
+    const uint8_t *in;    // [B][H][W][3]
+    const int32_t *kind;  // [B] cast kinds or nullptr
+    const float *A;       // [B][3]
+    const double *t;      // [B][H][W]
+};
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
-                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false);
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false,
+                               const uint32_t *d_only = nullptr);
 size_t tail_ws_bytes(Shape s, int tx, int ty);
 // d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,
                       Shape s, double clip, int tx, int ty, int gamma_mode, double gamma, uint8_t *d_out_u8,
-                      float *d_out_f32, void *ws, hipStream_t st);
+                      float *d_out_f32, void *ws, hipStream_t st, const RestoreSrc *src = nullptr);
 int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
                       int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
 // ES surface (float64): recover_image (ES:237-249) -> planar float64 + first select digit; color_enhancement

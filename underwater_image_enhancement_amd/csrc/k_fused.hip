@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "devutil.h"
+#include "restore.h"
 
 namespace uwie {
 
@@ -25,24 +26,25 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 #define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 // grid (nblk, B), block 256.  LIN: the histogram is over lin_digit() (select_lin_*), else over the top 11 key bits.
+// planar == nullptr: histogram only (the consumers recompute the image from S, restore.h); ghist == nullptr: image
+// only; only != nullptr: images none of whose three planes is flagged are skipped.
 template <bool LIN>
-__global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
-                                                             const float *__restrict__ A, const double *__restrict__ t,
-                                                             int npx, float *__restrict__ planar,
-                                                             uint32_t *__restrict__ ghist)
+__global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
+                                                             uint32_t *__restrict__ ghist,
+                                                             const uint32_t *__restrict__ only)
 {
     constexpr int NB = LIN ? 2052 : 2048;
     __shared__ uint32_t h[3][NB];
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const int k = kind ? kind[b] : 0;
-    const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
-    const uint8_t *img = in + (size_t)b * npx * 3;
+    if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
+    if (ghist) {
+        for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
+        __syncthreads();
+    }
+    RestoreImg R;
+    R.init(S, b, (size_t)npx);
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
-    const bool ag = px_atten(k, 1), ab = px_atten(k, 2);
-    const double *trow = t + (size_t)b * npx;
     // The first digit (sign, exponent, 2 mantissa bits) takes a dozen values on a whole frame, so plain LDS atomics
     // serialise 64 deep.  Each thread counts runs of equal digits in registers and touches LDS only when the digit
     // changes (neighbouring pixels almost always share it).
@@ -57,41 +59,32 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(const uint8_t *__re
     };
     for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
         const int n = min(4, npx - p);
-        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
-        double tv[4];
-        if (aligned && n == 4) {
-            const double2 ta = *reinterpret_cast<const double2 *>(trow + p), tb = *reinterpret_cast<const double2 *>(trow + p + 2);
-            tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
-        } else {
-            for (int i = 0; i < 4; ++i) tv[i] = i < n ? trow[p + i] : 1.0;
-        }
-        float r0[4], r1[4], r2[4];
+        float r[3][4];
+        R.four(p, n, r);
+        if (ghist) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d0 = px_val(v.r[i], false) - a0;
-            const float d1 = px_val(v.g[i], ag) - a1;
-            const float d2 = px_val(v.b[i], ab) - a2;
-            r0[i] = clip01((float)((double)d0 / tv[i] + (double)a0));
-            r1[i] = clip01((float)((double)d1 / tv[i] + (double)a1));
-            r2[i] = clip01((float)((double)d2 / tv[i] + (double)a2));
-            if (i < n) {
-                bump(0, LIN ? lin_digit(r0[i]) : f32_key(r0[i]) >> 21);
-                bump(1, LIN ? lin_digit(r1[i]) : f32_key(r1[i]) >> 21);
-                bump(2, LIN ? lin_digit(r2[i]) : f32_key(r2[i]) >> 21);
+            for (int i = 0; i < 4; ++i) {
+                if (i < n) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) bump(c, LIN ? lin_digit(r[c][i]) : f32_key(r[c][i]) >> 21);
+                }
             }
         }
-        if (aligned && n == 4) {
-            *reinterpret_cast<float4 *>(o0 + p) = make_float4(r0[0], r0[1], r0[2], r0[3]);
-            *reinterpret_cast<float4 *>(o1 + p) = make_float4(r1[0], r1[1], r1[2], r1[3]);
-            *reinterpret_cast<float4 *>(o2 + p) = make_float4(r2[0], r2[1], r2[2], r2[3]);
-        } else {
-            for (int i = 0; i < n; ++i) {
-                o0[p + i] = r0[i];
-                o1[p + i] = r1[i];
-                o2[p + i] = r2[i];
+        if (planar) {
+            if (aligned && n == 4) {
+                *reinterpret_cast<float4 *>(o0 + p) = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+                *reinterpret_cast<float4 *>(o1 + p) = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+                *reinterpret_cast<float4 *>(o2 + p) = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+            } else {
+                for (int i = 0; i < n; ++i) {
+                    o0[p + i] = r[0][i];
+                    o1[p + i] = r[1][i];
+                    o2[p + i] = r[2][i];
+                }
             }
         }
     }
+    if (!ghist) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
@@ -141,10 +134,12 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *ws
     return incl;
 }
 
-// grid (tx*ty, B), block 256
+// grid (tx*ty, B), block 256.  SRC: the restored image is recomputed from S (restore.h) instead of read from planar.
+template <bool SRC>
 __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__restrict__ T, const float *__restrict__ planar,
-                                                         const float *__restrict__ pct, int pct_stride, float eps, int two,
-                                                         ClaheGeom g, uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
+                                                         RestoreSrc src, const float *__restrict__ pct, int pct_stride,
+                                                         float eps, int two, ClaheGeom g, uint8_t *__restrict__ lab,
+                                                         uint8_t *__restrict__ lut)
 {
     __shared__ uint32_t h[4][256];
     __shared__ uint32_t wsum[4];
@@ -160,6 +155,8 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     __syncthreads();
     const int npx = g.H * g.W;
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
+    RestoreImg R;
+    if (SRC) R.init(src, b, (size_t)npx);
     uint8_t *labimg = lab + (size_t)b * npx * 3;
     const int ty = tile / g.tx, txi = tile % g.tx;
     const int area = g.tw * g.th;
@@ -184,7 +181,16 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
         const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr
         const int x0 = x_lo + 4 * xg, n = min(4, x_hi - x0), p = (y_lo + row) * g.W + x0;
         float v0[4], v1[4], v2[4];
-        if (n == 4) {
+        if (SRC) {
+            float r[3][4];
+            R.four(p, n, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v0[i] = r[0][i];
+                v1[i] = r[1][i];
+                v2[i] = r[2][i];
+            }
+        } else if (n == 4) {
             *reinterpret_cast<uint4 *>(v0) = *reinterpret_cast<const u128_unaligned *>(r0 + p);
             *reinterpret_cast<uint4 *>(v1) = *reinterpret_cast<const u128_unaligned *>(r1 + p);
             *reinterpret_cast<uint4 *>(v2) = *reinterpret_cast<const u128_unaligned *>(r2 + p);
@@ -233,7 +239,15 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
             if (ey < g.H && ex < g.W) continue;
             const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
             uint32_t L, a, bb;
-            to_lab(r0[p], r1[p], r2[p], L, a, bb);
+            float e0, e1, e2;
+            if (SRC) {
+                R.pixel(p, e0, e1, e2);
+            } else {
+                e0 = r0[p];
+                e1 = r1[p];
+                e2 = r2[p];
+            }
+            to_lab(e0, e1, e2, L, a, bb);
             atomicAdd(&h[w][L], 1u);
         }
     }
@@ -504,7 +518,7 @@ float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode ==
 }  // namespace
 
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
-                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear)
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only)
 {
     // 24.6 KB of LDS per block: six blocks per CU, 1536 resident on the chip.  Enough blocks for several full rounds
     // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
@@ -513,12 +527,13 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     nblk = nblk < 16 ? 16 : nblk > 1024 ? 1024 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
+    const RestoreSrc S{d_in, d_kind, d_A, d_t};
     if (linear)
-        UWIE_LAUNCH(k_restore_planar_hist<true>, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
-                    d_planar, d_ghist);
+        UWIE_LAUNCH(k_restore_planar_hist<true>, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist,
+                    d_only);
     else
-        UWIE_LAUNCH(k_restore_planar_hist<false>, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
-                    d_planar, d_ghist);
+        UWIE_LAUNCH(k_restore_planar_hist<false>, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist,
+                    d_only);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -555,14 +570,18 @@ size_t tail_ws_bytes(Shape s, int tx, int ty)
 
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,
                       Shape s, double clip, int tx, int ty, int gamma_mode, double gamma, uint8_t *d_out_u8,
-                      float *d_out_f32, void *ws, hipStream_t st)
+                      float *d_out_f32, void *ws, hipStream_t st, const RestoreSrc *src)
 {
     Carver c(ws);
     uint8_t *lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
     uint8_t *lab = c.take<uint8_t>((size_t)s.B * s.npx() * 3);
     const ClaheGeom g = make_geom(s, clip, tx, ty);
-    UWIE_LAUNCH(k_stretch_lab_lut, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, d_pct, pct_stride, eps, two,
-                g, lab, lut);
+    if (src)
+        UWIE_LAUNCH(k_stretch_lab_lut<true>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, *src, d_pct,
+                    pct_stride, eps, two, g, lab, lut);
+    else
+        UWIE_LAUNCH(k_stretch_lab_lut<false>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, RestoreSrc{},
+                    d_pct, pct_stride, eps, two, g, lab, lut);
     UWIE_LAUNCH_CHECK();
     // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
     const int cells = (tx + 1) * (ty + 1);

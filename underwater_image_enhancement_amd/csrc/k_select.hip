@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "devutil.h"
+#include "restore.h"
 
 namespace uwie {
 
@@ -557,6 +558,83 @@ __global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ v
     flush(true);
 }
 
+// The same sweep when the planes are not stored: grid (blocks, B), the block recomputes its pixels' three restored
+// values from the frame and the transmission (restore.h, 11 instead of 12 bytes per pixel and no stored copy) and
+// files each under its own channel's groups.  NG: most groups per channel (ranks of the call).
+template <int NG>
+__global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, LinState *__restrict__ st,
+                                                         float *__restrict__ lists, uint32_t cap)
+{
+    __shared__ float stg[3 * NG][kLinStage];
+    __shared__ uint32_t scount[3 * NG], sbase[3 * NG];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    LinState *s = st + 3 * b;
+    int ngc[3];
+    uint32_t gd[3][NG];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ngc[c] = min((int)s[c].ngroups, NG);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gd[c][g] = g < ngc[c] ? s[c].gbin[g] - 1 : kLinDone;
+    }
+    if (ngc[0] + ngc[1] + ngc[2] == 0) return;
+    if (tid < 3 * NG) scount[tid] = 0;
+    __syncthreads();
+    RestoreImg R;
+    R.init(S, b, (size_t)n);
+    const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
+    const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
+    auto take = [&](int c, float x, bool live) {
+        const uint32_t d = (live && x > 0.0f) ? (uint32_t)(x * 2048.0f) : 0xfffffffeu;  // see k_lin_collect
+        uint32_t idx = kLinDone;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) idx = d == gd[c][g] ? (uint32_t)g : idx;
+        if (idx != kLinDone) {
+            const uint32_t pos = atomicAdd(&scount[c * NG + idx], 1u);
+            if (pos < (uint32_t)kLinStage) stg[c * NG + idx][pos] = x;
+        }
+    };
+    auto flush = [&](bool force) {  // all threads of the block call
+        __syncthreads();
+        bool need = force;
+        for (int j = 0; j < 3 * NG; ++j) need = need || scount[j] > (uint32_t)(kLinStage * 3 / 4);
+        if (!need) return;  // block-uniform
+        if (tid < 3 * NG) {
+            const uint32_t c = scount[tid];
+            if (c) sbase[tid] = atomicAdd(&s[tid / NG].gcount[tid % NG], c > (uint32_t)kLinStage ? cap + 1 : c);
+        }
+        __syncthreads();
+        for (int j = 0; j < 3 * NG; ++j) {
+            const uint32_t c = min(scount[j], (uint32_t)kLinStage), base = sbase[j];
+            float *L = lists + ((size_t)(3 * b + j / NG) * kMaxRanks + (j % NG)) * cap;
+            for (uint32_t i = tid; i < c; i += 256)
+                if (base + i < cap) L[base + i] = stg[j][i];
+        }
+        __syncthreads();
+        if (tid < 3 * NG) scount[tid] = 0;
+        __syncthreads();
+    };
+    constexpr int U = 2;
+    for (int base = lo; base < hi; base += U * 1024) {  // block-uniform trip count
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * 1024 + tid * 4, m = min(4, hi - p);
+            if (m > 0) {
+                float r[3][4];
+                R.four(p, m, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    take(0, r[0][i], i < m);
+                    take(1, r[1][i], i < m);
+                    take(2, r[2][i], i < m);
+                }
+            }
+        }
+        flush(false);
+    }
+    flush(true);
+}
+
 // one block per (image, channel, query): the query is finished on its group's list by a 3-digit radix select
 __global__ void __launch_bounds__(256) k_lin_finish(const LinState *__restrict__ st, const float *__restrict__ lists,
                                                     uint32_t cap, float *__restrict__ os, uint32_t *__restrict__ flags)
@@ -633,12 +711,13 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
 
 // After the producer has filled the linear-digit histogram: scan -> one collecting sweep -> finish on the lists;
 // planes whose list overflowed (a heavy bin, e.g. a constant image) take the generic three sweeps.
-int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipStream_t st)
+int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc *src)
 {
     const int n = (int)s.npx(), nbc = s.B * 3;
     RankList ranks;
     ranks.n = 2 * plan.nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
+    UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
     UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags);
     UWIE_LAUNCH_CHECK();
@@ -646,11 +725,21 @@ int select_lin_run(const SelectPlan &plan, const float *d_planar, Shape s, hipSt
     int blocks = env_cb ? atoi(env_cb) : (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
-    UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
+    if (src) {
+        const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
+        UWIE_LAUNCH(k_lin_collect_src<4>, dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
+    } else {
+        UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
+    }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish, dim3(nbc, ranks.n), dim3(256), 0, st, lin, plan.lists, plan.cap, (float *)plan.os, plan.flags);
     UWIE_LAUNCH_CHECK();
-    // generic path for the flagged planes (its kernels return at once for the others)
+    // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
+    // flagged images are written out first
+    if (src) {
+        const int rc = launch_restore_planar_hist(src->in, src->kind, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags);
+        if (rc != UWIE_OK) return rc;
+    }
     UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));

@@ -3,33 +3,22 @@
 // enhancement_strategies.py:276-285) and the output quantisation (six_stadigy.py:430).
 #include "common.h"
 #include "devutil.h"
+#include "restore.h"
 
 namespace uwie {
 
 namespace {
 
-// result[:,:,c] = (img[:,:,c] - A[c]) / t + A[c]: float32 difference, float64 quotient and sum, float32 store; clip.
-__global__ void __launch_bounds__(256) k_restore(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
-                                                 const float *__restrict__ A, const double *__restrict__ t, int npx,
-                                                 float *__restrict__ out)
+// result[:,:,c] = (img[:,:,c] - A[c]) / t + A[c]: float32 difference, float64 quotient and sum, float32 store; clip
+// (restore.h: the same evaluation the fused tail uses, so the stage tests pin it).
+__global__ void __launch_bounds__(256) k_restore(RestoreSrc S, int npx, float *__restrict__ out)
 {
     const int b = blockIdx.y;
-    const int k = kind ? kind[b] : 0;
-    const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
-    const uint8_t *img = in + (size_t)b * npx * 3;
+    RestoreImg R;
+    R.init(S, b, (size_t)npx);
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        const double tv = t[(size_t)b * npx + p];
-        const float d0 = px_val(q[0], false) - a0;
-        const float d1 = px_val(q[1], px_atten(k, 1)) - a1;
-        const float d2 = px_val(q[2], px_atten(k, 2)) - a2;
-        const float r0 = (float)((double)d0 / tv + (double)a0);
-        const float r1 = (float)((double)d1 / tv + (double)a1);
-        const float r2 = (float)((double)d2 / tv + (double)a2);
         float *o = out + ((size_t)b * npx + p) * 3;
-        o[0] = fminf(fmaxf(r0, 0.0f), 1.0f);
-        o[1] = fminf(fmaxf(r1, 0.0f), 1.0f);
-        o[2] = fminf(fmaxf(r2, 0.0f), 1.0f);
+        R.pixel(p, o[0], o[1], o[2]);
     }
 }
 
@@ -80,8 +69,8 @@ __global__ void __launch_bounds__(256) k_quantise(const float *__restrict__ img,
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                    float *d_out, hipStream_t st)
 {
-    UWIE_LAUNCH(k_restore, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, d_in, d_kind, d_A, d_t, (int)s.npx(),
-                       d_out);
+    UWIE_LAUNCH(k_restore, dim3(grid_for(s.npx()), s.B), dim3(256), 0, st, RestoreSrc{d_in, d_kind, d_A, d_t},
+                (int)s.npx(), d_out);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

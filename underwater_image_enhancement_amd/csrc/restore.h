@@ -1,0 +1,109 @@
+// restore_image (six_stadigy.py:183-188) evaluated on the fly: J = clip((I - A) / t[..., None] + A, 0, 1) with I the
+// colour-corrected float32 frame, A float32 and t the float64 transmission, so the quotient and the sum are float64
+// and the result is rounded to float32 once (S6:188 astype).  Kernels that need the restored image more than once
+// recompute it from the 3 + 8 bytes per pixel it is made of instead of reading a 12-byte float32 copy.
+#pragma once
+#include "common.h"
+#include "devutil.h"
+
+namespace uwie {
+
+typedef uint32_t __attribute__((aligned(1))) u32_any;
+typedef double2 __attribute__((aligned(8))) double2_a8;
+
+struct RestoreImg {  // per image, in registers
+    const uint8_t *img;
+    const double *t;
+    float a[3];
+    bool att[3];
+    __device__ __forceinline__ void init(const RestoreSrc &S, int b, size_t npx)
+    {
+        const int k = S.kind ? S.kind[b] : 0;
+        img = S.in + (size_t)b * npx * 3;
+        t = S.t + (size_t)b * npx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = S.A[b * 3 + c];
+            att[c] = px_atten(k, c);
+        }
+    }
+    // px_norm_fast(u) == u / 255.0f for every byte (tests/test_cabi.py), so this is px_val() without the division
+    __device__ __forceinline__ float diff(uint32_t u, int c) const
+    {
+        const float x = px_norm_fast(u);
+        return (att[c] ? x * 0.85f : x) - a[c];
+    }
+    __device__ __forceinline__ float one(uint32_t u, int c, double tv) const
+    {
+        const float v = (float)((double)diff(u, c) / tv + (double)a[c]);
+        return fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+    // The three quotients of a pixel share the divisor.  The compiler expands a float64 division into v_rcp_f64, two
+    // Newton steps on the reciprocal y, q0 = n*y, r = fma(-d, q0, n), q = fma(r, y, q0) (Markstein: correctly rounded),
+    // wrapped in v_div_scale / v_div_fixup for operands near the ends of the exponent range.  For a divisor in
+    // [2^-100, 2^100] and a numerator that came from a float32 nothing is scaled or fixed up, so evaluating y once and the last
+    // three operations per channel gives the same bits as three divisions; other divisors take the division.
+    __device__ __forceinline__ static bool recip_ok(double tv) { return tv >= 0x1p-100 && tv <= 0x1p100; }
+    __device__ __forceinline__ static double recip(double tv)
+    {
+        double y = __builtin_amdgcn_rcp(tv);
+        y = fma(y, fma(-tv, y, 1.0), y);
+        return fma(y, fma(-tv, y, 1.0), y);
+    }
+    __device__ __forceinline__ float one_fast(uint32_t u, int c, double tv, double y) const
+    {
+        const double n = (double)diff(u, c), q0 = n * y;
+        const float v = (float)(fma(fma(-tv, q0, n), y, q0) + (double)a[c]);
+        return fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+    // pixels p .. p+3 (n of them exist); any alignment
+    __device__ __forceinline__ void four(int p, int n, float (&r)[3][4]) const
+    {
+        Px4 v;
+        double tv[4];
+        if (n == 4) {
+            const u32_any *w = reinterpret_cast<const u32_any *>(img + (size_t)p * 3);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            v.r[0] = w0 & 255; v.g[0] = (w0 >> 8) & 255; v.b[0] = (w0 >> 16) & 255;
+            v.r[1] = w0 >> 24; v.g[1] = w1 & 255; v.b[1] = (w1 >> 8) & 255;
+            v.r[2] = (w1 >> 16) & 255; v.g[2] = w1 >> 24; v.b[2] = w2 & 255;
+            v.r[3] = (w2 >> 8) & 255; v.g[3] = (w2 >> 16) & 255; v.b[3] = w2 >> 24;
+            const double2_a8 ta = *reinterpret_cast<const double2_a8 *>(t + p), tb = *reinterpret_cast<const double2_a8 *>(t + p + 2);
+            tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
+        } else {
+            v = load_px4(img + (size_t)p * 3, n, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = i < n ? t[p + i] : 1.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (recip_ok(tv[i])) {
+                const double y = recip(tv[i]);
+                r[0][i] = one_fast(v.r[i], 0, tv[i], y);
+                r[1][i] = one_fast(v.g[i], 1, tv[i], y);
+                r[2][i] = one_fast(v.b[i], 2, tv[i], y);
+            } else {
+                r[0][i] = one(v.r[i], 0, tv[i]);
+                r[1][i] = one(v.g[i], 1, tv[i]);
+                r[2][i] = one(v.b[i], 2, tv[i]);
+            }
+        }
+    }
+    __device__ __forceinline__ void pixel(int p, float &r0, float &r1, float &r2) const
+    {
+        const uint8_t *q = img + (size_t)p * 3;
+        const double tv = t[p];
+        if (recip_ok(tv)) {
+            const double y = recip(tv);
+            r0 = one_fast(q[0], 0, tv, y);
+            r1 = one_fast(q[1], 1, tv, y);
+            r2 = one_fast(q[2], 2, tv, y);
+        } else {
+            r0 = one(q[0], 0, tv);
+            r1 = one(q[1], 1, tv);
+            r2 = one(q[2], 2, tv);
+        }
+    }
+};
+
+}  // namespace uwie
