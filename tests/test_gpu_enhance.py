@@ -268,7 +268,7 @@ def test_select_paths_agree(uw, orc, monkeypatch):
     """The percentile selection of strategies 1-3 has three routes: linear first digit with collected candidates (default),
     its fallback to the generic sweeps when a candidate list overflows (forced here with a tiny list capacity, and hit for
     real by a nearly constant frame), and the generic three-digit sweeps alone; strategies 1-2 run them either on the
-    stored planes (default) or on the restored image recomputed per sweep (UWIE_RESTORE_RECOMPUTE=1).  All must give the
+    the restored image recomputed per sweep (default) or on stored planes (UWIE_RESTORE_STORE=1).  All must give the
     oracle's bytes."""
     rng = np.random.default_rng(404)
     noisy = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
@@ -276,20 +276,28 @@ def test_select_paths_agree(uw, orc, monkeypatch):
     flatish[:] = (90, 140, 180)
     flatish[::7, ::5] = rng.integers(0, 256, flatish[::7, ::5].shape, dtype=np.uint8)
     odd = rng.integers(0, 256, (131, 203, 3), dtype=np.uint8)  # pixel count and tile widths not multiples of 4
+    yy, xx = np.mgrid[0:520, 0:1000]  # > 262144 pixels: the prediction works from a subsample of the rows
+    wide = np.stack([40 + 0.1 * xx + 0.2 * yy, 60 + 0.15 * xx, 200 - 0.1 * yy], -1) + rng.normal(0, 12, (520, 1000, 3))
+    wide = np.clip(wide, 0, 255).astype(np.uint8)
     big = np.empty((700, 720, 3), np.uint8)  # a block meets > 512 candidates of one bin in one step: LDS stage overflow
     big[:] = (60, 120, 200)
     big[::11, ::13] = rng.integers(0, 256, big[::11, ::13].shape, dtype=np.uint8)
     want_big = orc.enhance_u8(big, 2)
     for store in ("0", "1"):
-        monkeypatch.setenv("UWIE_RESTORE_RECOMPUTE", store)
-        for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd)):
+        monkeypatch.setenv("UWIE_RESTORE_STORE", store)
+        for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd), ("wide", wide)):
             for k in (1, 2, 3):
                 want = orc.enhance_u8(u8, k)
-                check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}, recompute={store}")
+                check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}, store={store}")
                 monkeypatch.setenv("UWIE_LIN_CAP", "16")
-                check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, recompute={store}")
+                check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, store={store}")
                 monkeypatch.delenv("UWIE_LIN_CAP")
-        check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, recompute={store}")
-    monkeypatch.delenv("UWIE_RESTORE_RECOMPUTE")
+                if k != 3:  # the producer files predicted windows for strategies 1-2: off, still covering, missing
+                    for knob, val in (("UWIE_LIN_NO_PREDICT", "1"), ("UWIE_LIN_PREDICT_SHIFT", "2"), ("UWIE_LIN_PREDICT_SHIFT", "400")):
+                        monkeypatch.setenv(knob, val)
+                        check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
+                        monkeypatch.delenv(knob)
+        check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")
+    monkeypatch.delenv("UWIE_RESTORE_STORE")
     batch = np.stack([noisy[:120, :200], flatish[:120, :200], noisy[30:150, 10:210]])
     assert np.array_equal(uw.enhance(batch, strategy=2), np.stack([uw.enhance(f, strategy=2) for f in batch]))

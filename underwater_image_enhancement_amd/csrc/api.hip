@@ -164,14 +164,16 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
         UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
     } else {
-        // UWIE_RESTORE_RECOMPUTE=1 (strategies 1 and 2): the restored image is never stored, the histogram sweep, the
-        // collecting sweep and the stretch each recompute it from the frame and t (restore.h; 36 instead of 50 bytes
-        // per pixel over the three).  Measured slower at 4K x 64 (5.7 vs 5.4 ms for the three: ~90 VALU operations per
-        // pixel and sweep meet the HBM time of 11 B/px), so it is opt-in: it is the mode for a tight workspace.
-        const char *env_rc = getenv("UWIE_RESTORE_RECOMPUTE");  // read per call: the tests compare both modes
-        recompute = k != 3 && env_rc && atoi(env_rc) == 1;
-        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true));
+        // Strategies 1 and 2 never store the restored image: the histogram sweep (which also files the elements of the
+        // predicted target bins, select_lin_begin) and the stretch each recompute it from the frame and t (restore.h:
+        // 11 + 14 bytes per pixel instead of 23 + 15, and no collecting sweep).  P.F is only written for images whose
+        // selection falls back to the generic sweeps.  UWIE_RESTORE_STORE=1 keeps the stored planes (4K x 64: 17.9 vs
+        // 17.5 ms per step).
+        const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call: the tests compare both modes
+        recompute = k != 3 && !(env_store && atoi(env_store) == 1);
+        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, k != 3 ? &src : nullptr));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
+                                            k != 3 ? &plan : nullptr));
         UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
     }
     if (k == 3) {

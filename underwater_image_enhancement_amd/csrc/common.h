@@ -202,9 +202,10 @@ struct SelectPlan {
     bool is64;
     // linear-digit path (select_lin_*): per (image, channel) state, candidate lists and fallback flags
     void *lin;
-    float *lists;          // [B*3][8][cap]
+    float *lists;          // [B*3][kLinLists][cap]
     uint32_t *flags;       // [B*3] 1 = a candidate list overflowed, use the generic sweeps
     uint32_t cap;
+    bool predicted;        // the producer files the predicted windows: the collecting sweep is the rare fallback
     uint32_t ranks[2 * kMaxPct];
 };
 // Selection on clipped [0, 1] float32 planes with ONE sweep after the producer's histogram: the first digit is a linear
@@ -219,8 +220,25 @@ __host__ __device__ inline uint32_t lin_digit(float x)
     const uint32_t d = (uint32_t)(x * 2048.0f);  // exact product, truncation: monotone in x
     return 1 + (d > 2047u ? 2047u : d);
 }
-int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+// Per (image, channel) state of the linear-digit selection.  With a prediction (select_lin_begin(..., predict)) the
+// producer already files the elements of two windows of bins, each around the predicted position of a percentile's
+// ranks, into one list per window during its own sweep; the scan then checks the prediction against the exact
+// histogram, and only planes it missed need the collecting sweep (whose groups reuse the lists).
+constexpr int kLinLists = 2 * kMaxPct;   // candidate lists per (image, channel)
+constexpr uint32_t kLinNoWin = 0x80000000u;
+struct LinState {
+    uint32_t rr[2 * kMaxPct];    // rank of the query inside its bin
+    uint32_t qbin[2 * kMaxPct];  // bin of the query
+    uint32_t gid[2 * kMaxPct];   // list of the query; kLinDone: answered by the scan
+    uint32_t gbin[2 * kMaxPct];  // bin of the collecting sweep's group g (list g)
+    uint32_t gcount[kLinLists];  // elements filed in each list
+    uint32_t ngroups;            // groups the collecting sweep has to fill (0: the prediction covered every query)
+    uint32_t wlo[2], wspan[2];   // predicted windows: bins wlo .. wlo + wspan (wlo = kLinNoWin: none), list = window
+};
 struct RestoreSrc;
+// predict != nullptr (nq <= 2): the target bins are predicted from a subsample of the restored image (k_lin_sample)
+int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
+                     const RestoreSrc *predict = nullptr);
 // src != nullptr: the values are recomputed from *src; d_planar is then only written (and read back) for planes that
 // fall back to the generic sweeps
 int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc *src = nullptr);
@@ -246,9 +264,10 @@ struct RestoreSrc {
     const float *A;       // [B][3]
     const double *t;      // [B][H][W]
 };
+// plan != nullptr: the linear-digit histogram goes to plan->ghist and the elements of the predicted windows to the lists
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                                float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false,
-                               const uint32_t *d_only = nullptr);
+                               const uint32_t *d_only = nullptr, const SelectPlan *plan = nullptr);
 size_t tail_ws_bytes(Shape s, int tx, int ty);
 // d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,

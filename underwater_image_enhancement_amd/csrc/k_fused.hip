@@ -28,63 +28,114 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 // grid (nblk, B), block 256.  LIN: the histogram is over lin_digit() (select_lin_*), else over the top 11 key bits.
 // planar == nullptr: histogram only (the consumers recompute the image from S, restore.h); ghist == nullptr: image
 // only; only != nullptr: images none of whose three planes is flagged are skipped.
-template <bool LIN>
+// COLLECT (with LIN): values whose digit lies in one of the plane's two predicted windows (LinState::wlo, wspan) are
+// filed into the window's list on the way: staged in LDS, moved out in batches (a block reserves list space once per
+// batch and window).
+constexpr int kWinStage = 256;
+template <bool LIN, bool COLLECT>
 __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist,
-                                                             const uint32_t *__restrict__ only)
+                                                             const uint32_t *__restrict__ only, LinState *__restrict__ lin,
+                                                             float *__restrict__ lists, uint32_t cap)
 {
     constexpr int NB = LIN ? 2052 : 2048;
+    constexpr int NS = COLLECT ? 6 : 1, SN = COLLECT ? kWinStage : 1;
     __shared__ uint32_t h[3][NB];
+    __shared__ float stg[NS][SN];
+    __shared__ uint32_t scount[NS], sbase[NS];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
     if (ghist) {
         for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
+        if (tid < NS) scount[tid] = 0;
         __syncthreads();
     }
     RestoreImg R;
     R.init(S, b, (size_t)npx);
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
+    uint32_t wlo[3][2], wspan[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            wlo[c][w] = COLLECT ? lin[3 * b + c].wlo[w] : kLinNoWin;
+            wspan[c][w] = COLLECT ? lin[3 * b + c].wspan[w] : 0;
+        }
     // The first digit (sign, exponent, 2 mantissa bits) takes a dozen values on a whole frame, so plain LDS atomics
     // serialise 64 deep.  Each thread counts runs of equal digits in registers and touches LDS only when the digit
     // changes (neighbouring pixels almost always share it).
     uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0};
-    auto bump = [&](int c, uint32_t d) {
+    auto bump = [&](int c, uint32_t d, float x) {
         if (d != cur[c]) {
             if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
             cur[c] = d;
             run[c] = 0;
         }
         ++run[c];
+        if (COLLECT) {
+            const bool ia = d - wlo[c][0] <= wspan[c][0], ib = d - wlo[c][1] <= wspan[c][1];  // (disjoint)
+            if (ia || ib) {
+                const int j = c * 2 + (ia ? 0 : 1);
+                const uint32_t pos = atomicAdd(&scount[j], 1u);
+                if (pos < (uint32_t)SN) stg[j][pos] = x;  // (a fuller stage is caught by flush(): those lists overflow)
+            }
+        }
     };
-    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
+    auto flush = [&](bool force) {  // all threads of the block call
+        __syncthreads();
+        bool need = force;
+        for (int j = 0; j < NS; ++j) need = need || scount[j] > (uint32_t)(SN * 3 / 4);
+        if (!need) return;  // block-uniform
+        if (tid < NS) {
+            const uint32_t c = scount[tid];  // a stage that lost elements makes its list look overfull: generic sweeps
+            if (c) sbase[tid] = atomicAdd(&lin[3 * b + (tid >> 1)].gcount[tid & 1], c > (uint32_t)SN ? cap + 1 : c);
+        }
+        __syncthreads();
+        for (int j = 0; j < NS; ++j) {
+            const uint32_t c = min(scount[j], (uint32_t)SN), base = sbase[j];
+            float *L = lists + ((size_t)(3 * b + (j >> 1)) * kLinLists + (j & 1)) * cap;
+            for (uint32_t i = tid; i < c; i += 256)
+                if (base + i < cap) L[base + i] = stg[j][i];
+        }
+        __syncthreads();
+        if (tid < NS) scount[tid] = 0;
+        __syncthreads();
+    };
+    const int step = gridDim.x * 1024, iters = (npx + step - 1) / step;  // block-uniform trip count
+    for (int it = 0; it < iters; ++it) {
+        const int p = it * step + (blockIdx.x * 256 + tid) * 4;
         const int n = min(4, npx - p);
-        float r[3][4];
-        R.four(p, n, r);
-        if (ghist) {
+        if (n > 0) {
+            float r[3][4];
+            R.four(p, n, r);
+            if (ghist) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < n) {
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) bump(c, LIN ? lin_digit(r[c][i]) : f32_key(r[c][i]) >> 21);
+                        for (int c = 0; c < 3; ++c) bump(c, LIN ? lin_digit(r[c][i]) : f32_key(r[c][i]) >> 21, r[c][i]);
+                    }
+                }
+            }
+            if (planar) {
+                if (aligned && n == 4) {
+                    *reinterpret_cast<float4 *>(o0 + p) = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+                    *reinterpret_cast<float4 *>(o1 + p) = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+                    *reinterpret_cast<float4 *>(o2 + p) = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
+                } else {
+                    for (int i = 0; i < n; ++i) {
+                        o0[p + i] = r[0][i];
+                        o1[p + i] = r[1][i];
+                        o2[p + i] = r[2][i];
+                    }
                 }
             }
         }
-        if (planar) {
-            if (aligned && n == 4) {
-                *reinterpret_cast<float4 *>(o0 + p) = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
-                *reinterpret_cast<float4 *>(o1 + p) = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
-                *reinterpret_cast<float4 *>(o2 + p) = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
-            } else {
-                for (int i = 0; i < n; ++i) {
-                    o0[p + i] = r[0][i];
-                    o1[p + i] = r[1][i];
-                    o2[p + i] = r[2][i];
-                }
-            }
-        }
+        if (COLLECT) flush(false);
     }
     if (!ghist) return;
+    if (COLLECT) flush(true);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
@@ -518,7 +569,8 @@ float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode ==
 }  // namespace
 
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
-                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only)
+                               float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only,
+                               const SelectPlan *plan)
 {
     // 24.6 KB of LDS per block: six blocks per CU, 1536 resident on the chip.  Enough blocks for several full rounds
     // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
@@ -528,12 +580,21 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     const RestoreSrc S{d_in, d_kind, d_A, d_t};
-    if (linear)
-        UWIE_LAUNCH(k_restore_planar_hist<true>, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist,
-                    d_only);
-    else
-        UWIE_LAUNCH(k_restore_planar_hist<false>, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist,
-                    d_only);
+    const dim3 grid(nblk, s.B);
+    const auto k_restore_hist_collect = k_restore_planar_hist<true, true>;  // (names as the profiler reports them)
+    const auto k_restore_hist_lin = k_restore_planar_hist<true, false>;
+    const auto k_restore_hist_key = k_restore_planar_hist<false, false>;
+    if (plan) {
+        UWIE_REQUIRE(linear && d_ghist == plan->ghist, "restore: a selection plan goes with its own linear histogram");
+        UWIE_LAUNCH(k_restore_hist_collect, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                    (LinState *)plan->lin, plan->lists, plan->cap);
+    } else if (linear) {
+        UWIE_LAUNCH(k_restore_hist_lin, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                    (LinState *)nullptr, (float *)nullptr, 0u);
+    } else {
+        UWIE_LAUNCH(k_restore_hist_key, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                    (LinState *)nullptr, (float *)nullptr, 0u);
+    }
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

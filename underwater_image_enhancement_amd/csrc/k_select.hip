@@ -382,13 +382,6 @@ int lerp_t(const SelectPlan &plan, Shape s, V *d_out, hipStream_t st)
 // ===================================================================================== linear-digit selection
 namespace {
 
-struct LinState {              // one per (image, channel)
-    uint32_t rr[kMaxRanks];    // rank of the query inside its bin
-    uint32_t gid[kMaxRanks];   // group (distinct target bin) of the query; kLinDone: answered by the scan
-    uint32_t gbin[kMaxRanks];  // bin of the group
-    uint32_t gcount[kMaxRanks];  // elements collected for the group
-    uint32_t ngroups;
-};
 constexpr uint32_t kLinDone = 0xffffffffu;
 constexpr int kLinStage = 512;  // candidates a block stages in LDS per group before it reserves list space
 
@@ -437,10 +430,84 @@ __device__ void block_find_digit(const uint32_t *h, int nbins, uint32_t rank, ui
     __syncthreads();
 }
 
+constexpr int kLinSampleOff = 4096;  // the sample histogram of a plane lives behind the producer's in its ghist group
+
+// grid (blocks, B): linear-digit histogram of the restored image on every stride-th group of four pixels (ngs groups;
+// the frame as one flat array, so the sample is spread over rows and columns alike)
+__global__ void __launch_bounds__(256) k_lin_sample(RestoreSrc S, int npx, int stride, int ngs, uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t h[3][kLinBins];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < 3 * kLinBins; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    RestoreImg R;
+    R.init(S, b, (size_t)npx);
+    for (int i = blockIdx.x * 256 + tid; i < ngs; i += gridDim.x * 256) {
+        float r[3][4];
+        R.four((i * stride + stride / 2) * 4, 4, r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(&h[c][lin_digit(r[c][j])], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * kLinBins; i += 256) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / kLinBins) * kSelGroupStride + kLinSampleOff + (i % kLinBins)], c);
+    }
+}
+
+// one block per (image, channel): clears the state; with a sample (ns > 0) the window of percentile j spans the bins
+// that hold the sample ranks r_j*ns/n -+ delta, delta = 4 binomial standard deviations of the sample rank (+2); windows
+// that touch are merged.  shift: test knob, moves the windows up by that many bins.
+__global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
+                                                     RankList ranks, uint32_t n, uint32_t ns, int shift)
+{
+    __shared__ uint32_t h[kLinBins], wsum[4], found[2], wl[2], wh[2];
+    const int bc = blockIdx.x, tid = threadIdx.x;
+    if (tid < 2) { wl[tid] = kLinNoWin; wh[tid] = 0; }
+    if (ns > 0) {
+        const uint32_t *gh = ghist + (size_t)bc * kSelGroupStride + kLinSampleOff;
+        for (int i = tid; i < kLinBins; i += 256) h[i] = gh[i];
+        __syncthreads();
+        for (int j = 0; j < ranks.n / 2 && j < 2; ++j) {
+            const double p = (double)ranks.r[2 * j] / (double)n, sd = sqrt((double)ns * p * (1.0 - p));
+            const double c0 = (double)ranks.r[2 * j] * ns / n, c1 = (double)ranks.r[2 * j + 1] * ns / n, delta = 4.0 * sd + 2.0;
+            const uint32_t rlo = (uint32_t)fmax(c0 - delta, 0.0), rhi = (uint32_t)fmin(c1 + delta, (double)ns - 1.0);
+            uint32_t dlo, dhi, rr;
+            block_find_digit(h, kLinBins, rlo, wsum, found, dlo, rr);
+            block_find_digit(h, kLinBins, rhi, wsum, found, dhi, rr);
+            if (tid == 0) {  // interior bins only: the scan answers the bins of exact 0 and exact 1 by itself
+                wl[j] = (uint32_t)min(max((int)dlo + shift, 1), kLinBins - 2);
+                wh[j] = (uint32_t)min(max((int)dhi + shift, (int)wl[j]), kLinBins - 2);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        LinState s;
+        for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.qbin[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; }
+        for (int g = 0; g < kLinLists; ++g) s.gcount[g] = 0;
+        s.ngroups = 0;
+        if (wl[0] != kLinNoWin && wl[1] != kLinNoWin && wl[1] <= wh[0] + 1) {  // touching windows: one
+            wh[0] = max(wh[0], wh[1]);
+            wl[0] = min(wl[0], wl[1]);
+            wl[1] = kLinNoWin;
+        }
+        for (int w = 0; w < 2; ++w) {
+            s.wlo[w] = wl[w];
+            s.wspan[w] = wl[w] == kLinNoWin ? 0 : wh[w] - wl[w];
+        }
+        st[bc] = s;
+    }
+}
+
 // one block per (image, channel): the bin of every rank from the producer's histogram; ranks in the bins of exact
-// 0 / exact 1 are answered here
+// 0 / exact 1 are answered here.  A plane all of whose other queries fall into the predicted windows is done with
+// collecting (ngroups = 0, gid = the window's list); otherwise its queries are grouped by bin for the collecting sweep.
 __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
-                                                  RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags)
+                                                  RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags,
+                                                  uint32_t cap)
 {
     __shared__ uint32_t h[kLinBins], wsum[4], found[2], qbin[kMaxRanks], qrr[kMaxRanks];
     const int bc = blockIdx.x, tid = threadIdx.x;
@@ -454,20 +521,35 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
     }
     __syncthreads();
     if (tid == 0) {
-        LinState s;
-        uint32_t ng = 0;
-        for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; s.gcount[q] = 0; }
+        LinState s = st[bc];
+        bool covered = true;
+        for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.qbin[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; }
         for (int q = 0; q < ranks.n; ++q) {
             s.rr[q] = qrr[q];
+            s.qbin[q] = qbin[q];
             if (qbin[q] == 0 || qbin[q] == kLinBins - 1) {  // every element of these bins is 0 resp. 1
                 os[bc * kMaxRanks + q] = qbin[q] == 0 ? 0.0f : 1.0f;
                 continue;
             }
-            uint32_t g = 0;
-            for (; g < ng; ++g)
-                if (s.gbin[g] == qbin[q]) break;
-            if (g == ng) s.gbin[ng++] = qbin[q];
-            s.gid[q] = g;
+            int w = -1;
+            if (qbin[q] - s.wlo[0] <= s.wspan[0]) w = 0;
+            else if (qbin[q] - s.wlo[1] <= s.wspan[1]) w = 1;
+            if (w >= 0 && s.gcount[w] > cap) w = -1;  // the window met a heavy bin: the target bin alone may still fit
+            if (w >= 0) s.gid[q] = (uint32_t)w;
+            else covered = false;
+        }
+        uint32_t ng = 0;
+        if (!covered) {
+            for (int g = 0; g < kLinLists; ++g) s.gcount[g] = 0;
+            for (int q = 0; q < ranks.n; ++q) {
+                s.gid[q] = kLinDone;
+                if (qbin[q] == 0 || qbin[q] == kLinBins - 1) continue;
+                uint32_t g = 0;
+                for (; g < ng; ++g)
+                    if (s.gbin[g] == qbin[q]) break;
+                if (g == ng) s.gbin[ng++] = qbin[q];
+                s.gid[q] = g;
+            }
         }
         s.ngroups = ng;
         st[bc] = s;
@@ -493,7 +575,7 @@ __global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ v
     for (int g = 0; g < kMaxRanks; ++g) gd[g] = g < ng ? s->gbin[g] - 1 : kLinDone;
     if (tid < kMaxRanks) scount[tid] = 0;
     __syncthreads();
-    float *L = lists + (size_t)bc * kMaxRanks * cap;
+    float *L = lists + (size_t)bc * kLinLists * cap;
     const float *v = vals + (size_t)bc * n;
     const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
     const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
@@ -606,7 +688,7 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
         __syncthreads();
         for (int j = 0; j < 3 * NG; ++j) {
             const uint32_t c = min(scount[j], (uint32_t)kLinStage), base = sbase[j];
-            float *L = lists + ((size_t)(3 * b + j / NG) * kMaxRanks + (j % NG)) * cap;
+            float *L = lists + ((size_t)(3 * b + j / NG) * kLinLists + (j % NG)) * cap;
             for (uint32_t i = tid; i < c; i += 256)
                 if (base + i < cap) L[base + i] = stg[j][i];
         }
@@ -635,11 +717,12 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     flush(true);
 }
 
-// one block per (image, channel, query): the query is finished on its group's list by a 3-digit radix select
-__global__ void __launch_bounds__(256) k_lin_finish(const LinState *__restrict__ st, const float *__restrict__ lists,
-                                                    uint32_t cap, float *__restrict__ os, uint32_t *__restrict__ flags)
+// one block of 1024 per (image, channel, query): the query is finished on its list by a 3-digit radix select among
+// the list's elements of the query's bin (a window's list holds neighbouring bins too)
+__global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const float *__restrict__ lists,
+                                                     uint32_t cap, float *__restrict__ os, uint32_t *__restrict__ flags)
 {
-    __shared__ uint32_t h[2048], wsum[4], found[2];
+    __shared__ uint32_t h[2048], wsum[16], found[2];
     const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;  // grid (B*3, ranks)
     const LinState *s = st + bc;
     const uint32_t g = s->gid[q];
@@ -649,19 +732,30 @@ __global__ void __launch_bounds__(256) k_lin_finish(const LinState *__restrict__
         if (tid == 0) flags[bc] = 1;
         return;
     }
-    const float *L = lists + ((size_t)bc * kMaxRanks + g) * cap;
+    const float *L = lists + ((size_t)bc * kLinLists + g) * cap;
     uint32_t prefix = 0, r = s->rr[q];
+    const uint32_t tb = s->qbin[q];
     for (int p = 0; p < 3; ++p) {
         const int shift = Traits<float>::shift(p), bits = Traits<float>::bits(p), nbins = 1 << bits;
-        for (int i = tid; i < nbins; i += 256) h[i] = 0;
+        for (int i = tid; i < nbins; i += 1024) h[i] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += 256) {
-            const uint32_t key = f32_key(L[i]);
-            if (p == 0 || (key >> (shift + bits)) == prefix) atomicAdd(&h[(key >> shift) & (nbins - 1)], 1u);
+        for (uint32_t base = 0; base < cnt; base += 4096) {  // four loads in flight per thread
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = base + u * 1024 + tid;
+                x[u] = i < cnt ? L[i] : -1.0f;  // (bin 0, never a list's target)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t key = f32_key(x[u]);
+                if (lin_digit(x[u]) == tb && (p == 0 || (key >> (shift + bits)) == prefix))
+                    atomicAdd(&h[(key >> shift) & (nbins - 1)], 1u);
+            }
         }
         __syncthreads();
         uint32_t d, rr;
-        block_find_digit(h, nbins, r, wsum, found, d, rr);
+        block_find_digit(h, nbins, r, wsum, found, d, rr);  // (threads 256.. hold no bins there)
         prefix = (prefix << bits) | d;
         r = rr;
     }
@@ -679,13 +773,14 @@ LinBufs carve_lin(Carver &c, Shape s)
     const size_t nbc = (size_t)s.B * 3;
     b.lin = c.take<LinState>(nbc);
     b.flags = c.take<uint32_t>(nbc);
-    b.lists = c.take<float>(nbc * kMaxRanks * lin_cap(s));
+    b.lists = c.take<float>(nbc * kLinLists * lin_cap(s));
     return b;
 }
 
 }  // namespace
 
-int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan)
+int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
+                     const RestoreSrc *predict)
 {
     UWIE_REQUIRE(nq >= 1 && nq <= kMaxPct, "percentiles: 1..4 percentiles per call");
     const long long n = (long long)s.npx();
@@ -704,8 +799,35 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
     plan->is64 = false;
     for (int j = 0; j < nq; ++j)
         percentile_indices<float>(n, q_percent[j], &plan->ranks[2 * j], &plan->ranks[2 * j + 1], &plan->t[j]);
-    // only the first kLinBins counters of every (image, channel) are used by the producer
+    // only the first kLinBins counters of every (image, channel) are used by the producer (and kLinBins more by the sample)
     UWIE_HIP_CHECK(hipMemsetAsync(plan->ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    RankList ranks;
+    ranks.n = 2 * nq;
+    for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan->ranks[j];
+    uint32_t ns = 0;
+    // test knobs, read per call: UWIE_LIN_NO_PREDICT=1 switches the prediction off, UWIE_LIN_PREDICT_SHIFT=k moves the
+    // predicted windows k bins up (a large shift makes every prediction miss: collecting-sweep fallback)
+    const char *env_np = getenv("UWIE_LIN_NO_PREDICT"), *env_sh = getenv("UWIE_LIN_PREDICT_SHIFT");
+    const int shift = env_sh ? atoi(env_sh) : 0;
+    plan->predicted = false;
+    if (predict && nq <= 2 && !(env_np && atoi(env_np) == 1)) {
+        plan->predicted = true;
+        // ~128 K sample pixels per frame in evenly spaced groups of four (odd stride: no column is favoured): the
+        // sampling error of a 1 % rank is ~0.03 % of the frame, half a bin where the 2048 bins are equally full
+        const int ngroups = (int)(n / 4);
+        if (ngroups > 0) {
+            int stride = std::max(1, ngroups / 32768);
+            if (stride > 1) stride |= 1;
+            const int ngs = ngroups / stride;
+            ns = 4u * (uint32_t)ngs;
+            UWIE_LAUNCH(k_lin_sample, dim3(std::max(1, std::min(8, cdiv(ngs, 512))), s.B), dim3(256), 0, st, *predict, (int)n,
+                        stride, ngs, plan->ghist);
+            UWIE_LAUNCH_CHECK();
+        }
+    }
+    UWIE_LAUNCH(k_lin_predict, dim3(nbc), dim3(256), 0, st, (LinState *)plan->lin, plan->ghist, ranks, (uint32_t)n, ns,
+                shift);
+    UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
 
@@ -719,12 +841,16 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
     UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
-    UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags);
+    UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap);
     UWIE_LAUNCH_CHECK();
     static const char *env_cb = getenv("UWIE_COLLECT_BLOCKS");
     int blocks = env_cb ? atoi(env_cb) : (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    // after a prediction the sweep only serves the few planes it missed (a heavy bin next to the target made the
+    // window's list overflow, or the sample was off); its blocks return at once for the others, and the ones that work
+    // are alone on the chip: more, smaller blocks (4K x 64 with 4 such planes: 32 per plane 0.29 ms, 128: 0.12 ms)
+    if (plan.predicted && !env_cb) blocks = std::max(1, std::min(2 * blocks, cdiv(24576, nbc)));
     if (src) {
         const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
         UWIE_LAUNCH(k_lin_collect_src<4>, dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
@@ -732,7 +858,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
         UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
     }
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_lin_finish, dim3(nbc, ranks.n), dim3(256), 0, st, lin, plan.lists, plan.cap, (float *)plan.os, plan.flags);
+    UWIE_LAUNCH(k_lin_finish, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, plan.lists, plan.cap, (float *)plan.os, plan.flags);
     UWIE_LAUNCH_CHECK();
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
