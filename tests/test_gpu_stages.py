@@ -256,6 +256,27 @@ def test_restore_shared_reciprocal_is_the_division(dev):
     assert got.dtype == np.float32 and np.array_equal(got, want), int((got != want).sum())
 
 
+def test_stretch_shared_reciprocal_is_the_division(dev):
+    """The stretch divides every value of a plane by one denominator; the kernels keep the division's reciprocal and
+    redo only its last five operations per value (devutil.h StretchDiv).  Against NumPy's IEEE float32 division on 3 M
+    values per image: unit-range data, data with tiny and huge magnitudes (guarded: true division), a denominator near
+    eps, and one with an all-ones mantissa."""
+    rng = np.random.default_rng(78)
+    B, H, W = 4, 500, 500
+    img = rng.random((B, H, W, 3)).astype(np.float32)
+    img[1] = (np.exp(rng.uniform(np.log(1e-30), np.log(1e30), (H, W, 3))) * rng.choice([-1, 1], (H, W, 3))).astype(np.float32)
+    img[2] = np.float32(0.25) + (rng.random((H, W, 3)) * 3e-6).astype(np.float32)  # hi - lo of a few 1e-6
+    img[3, ::2] = np.float32(1.0) - np.float32(2.0 ** -24)
+    img[3, 1::2] = rng.random((H // 2, W, 3)).astype(np.float32) * np.float32(2.0 ** -24)
+    got = dev.stretch_f32(dev.tensor(img), 1.0, 99.0).cpu().numpy()
+    for b in range(B):
+        for c in range(3):  # six_stadigy.py:191-199, as the oracle restates it
+            plane = img[b, :, :, c]
+            lo, hi = np.percentile(plane, 1.0), np.percentile(plane, 99.0)
+            want = np.clip((plane - lo) / (hi - lo + 1e-6), 0, 1)
+            assert want.dtype == np.float32 and np.array_equal(got[b, :, :, c], want), (b, c, int((got[b, :, :, c] != want).sum()))
+
+
 # ------------------------------------------------------------------ percentiles / stretch / gamma / clahe on float images
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
 def test_percentiles_and_stretch_match_reference(dev, golden, tag):

@@ -69,6 +69,38 @@ __device__ __forceinline__ void store_px4(uint8_t *p, const uint32_t *r, const u
     }
 }
 
+// n / den for many n and one den (the percentile stretch: one denominator per image and channel).  The compiler expands
+// a correctly rounded float32 division into v_rcp_f32, one Newton step on the reciprocal y, q0 = n*y and two residual
+// corrections q = fma(fma(-den, q, n), y, q), wrapped in v_div_scale / v_div_fixup for operands near the ends of the
+// exponent range.  For den in [2^-24, 2^24] and n = 0 or |n| in [2^-60, 2^60] nothing is scaled and nothing is fixed up
+// except the sign of a zero, so keeping y and doing the last five operations per value gives the division's bits;
+// everything else takes the division (quot), or is known to be tiny either way (quot_unit).
+struct StretchDiv {
+    float den, y;
+    bool fast;
+    __device__ __forceinline__ void set(float d)
+    {
+        den = d;
+        fast = d >= 0x1p-24f && d <= 0x1p24f;
+        const float r = __builtin_amdgcn_rcpf(d);
+        y = fmaf(fmaf(-d, r, 1.0f), r, r);
+    }
+    __device__ __forceinline__ float seq(float n) const
+    {
+        float q = n * y;
+        q = fmaf(fmaf(-den, q, n), y, q);
+        return fmaf(fmaf(-den, q, n), y, q);
+    }
+    __device__ __forceinline__ float quot(float n) const  // any n
+    {
+        const float m = fabsf(n);
+        return fast && (m == 0.0f || (m >= 0x1p-60f && m <= 0x1p60f)) ? seq(n) : n / den;
+    }
+    // |n| <= 2 (differences of values in [0, 1]): below 2^-60 the quotient is under 2^-36 by either route, a zero byte
+    // after the x255 quantisation that follows in the fused kernels
+    __device__ __forceinline__ float quot_unit(float n) const { return fast ? seq(n) : n / den; }
+};
+
 // which channel color_correction attenuates for a cast kind (UWIE_CAST_*): greenish -> G, bluish -> B
 __device__ __forceinline__ bool px_atten(int kind, int c) { return kind != 0 && c == kind; }
 // (img * 255).astype(np.uint8): float32 product, truncation toward zero

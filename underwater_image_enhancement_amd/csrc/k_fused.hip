@@ -31,7 +31,7 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 // COLLECT (with LIN): values whose digit lies in one of the plane's two predicted windows (LinState::wlo, wspan) are
 // filed into the window's list on the way: staged in LDS, moved out in batches (a block reserves list space once per
 // batch and window).
-constexpr int kWinStage = 256;
+constexpr int kWinStage = 128;
 template <bool LIN, bool COLLECT>
 __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist,
@@ -42,16 +42,17 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     constexpr int NS = COLLECT ? 6 : 1, SN = COLLECT ? kWinStage : 1;
     __shared__ uint32_t h[3][NB];
     __shared__ float stg[NS][SN];
+    __shared__ float dtab[768];
     __shared__ uint32_t scount[NS], sbase[NS];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
     if (ghist) {
         for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
         if (tid < NS) scount[tid] = 0;
-        __syncthreads();
     }
-    RestoreImg R;
-    R.init(S, b, (size_t)npx);
+    RestoreImgT<true> R;
+    R.init(S, b, (size_t)npx, dtab);
+    __syncthreads();
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
     uint32_t wlo[3][2], wspan[3][2];
@@ -62,23 +63,35 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
             wlo[c][w] = COLLECT ? lin[3 * b + c].wlo[w] : kLinNoWin;
             wspan[c][w] = COLLECT ? lin[3 * b + c].wspan[w] : 0;
         }
-    // The first digit (sign, exponent, 2 mantissa bits) takes a dozen values on a whole frame, so plain LDS atomics
-    // serialise 64 deep.  Each thread counts runs of equal digits in registers and touches LDS only when the digit
-    // changes (neighbouring pixels almost always share it).
-    uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0};
+    // Key digits (sign, exponent, 2 mantissa bits) take a dozen values on a whole frame, so plain LDS atomics would
+    // serialise 64 deep: each thread counts runs of equal digits in registers and touches LDS only when the digit
+    // changes.  Linear digits spread over thousands of bins and change from pixel to pixel, so they go straight to LDS,
+    // except the two saturated bins (clipped 0 and 1 fill whole regions), which are counted in registers.
+    uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0}, sat0[3] = {0, 0, 0}, sat1[3] = {0, 0, 0};
     auto bump = [&](int c, uint32_t d, float x) {
-        if (d != cur[c]) {
-            if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
-            cur[c] = d;
-            run[c] = 0;
+        if (LIN) {
+            sat0[c] += d == 0;
+            sat1[c] += d == (uint32_t)kLinBins - 1;
+            if (d - 1 < (uint32_t)kLinBins - 2) atomicAdd(&h[c][d], 1u);
+        } else {
+            if (d != cur[c]) {
+                if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
+                cur[c] = d;
+                run[c] = 0;
+            }
+            ++run[c];
         }
-        ++run[c];
         if (COLLECT) {
             const bool ia = d - wlo[c][0] <= wspan[c][0], ib = d - wlo[c][1] <= wspan[c][1];  // (disjoint)
             if (ia || ib) {
                 const int j = c * 2 + (ia ? 0 : 1);
                 const uint32_t pos = atomicAdd(&scount[j], 1u);
-                if (pos < (uint32_t)SN) stg[j][pos] = x;  // (a fuller stage is caught by flush(): those lists overflow)
+                if (pos < (uint32_t)SN) {
+                    stg[j][pos] = x;
+                } else {  // a burst (a smooth region at the percentile's level): straight to the list
+                    const uint32_t idx = atomicAdd(&lin[3 * b + c].gcount[j & 1], 1u);
+                    if (idx < cap) lists[((size_t)(3 * b + c) * kLinLists + (j & 1)) * cap + idx] = x;
+                }
             }
         }
     };
@@ -88,8 +101,8 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         for (int j = 0; j < NS; ++j) need = need || scount[j] > (uint32_t)(SN * 3 / 4);
         if (!need) return;  // block-uniform
         if (tid < NS) {
-            const uint32_t c = scount[tid];  // a stage that lost elements makes its list look overfull: generic sweeps
-            if (c) sbase[tid] = atomicAdd(&lin[3 * b + (tid >> 1)].gcount[tid & 1], c > (uint32_t)SN ? cap + 1 : c);
+            const uint32_t c = min(scount[tid], (uint32_t)SN);
+            if (c) sbase[tid] = atomicAdd(&lin[3 * b + (tid >> 1)].gcount[tid & 1], c);
         }
         __syncthreads();
         for (int j = 0; j < NS; ++j) {
@@ -137,8 +150,16 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     if (!ghist) return;
     if (COLLECT) flush(true);
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c) {
         if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
+        if (LIN) {
+            const uint32_t z = wave_sum_u32(sat0[c]), o = wave_sum_u32(sat1[c]);
+            if ((tid & 63) == 0) {
+                if (z) atomicAdd(&h[c][0], z);
+                if (o) atomicAdd(&h[c][kLinBins - 1], o);
+            }
+        }
+    }
     __syncthreads();
     for (int i = tid; i < 3 * NB; i += 256) {
         const uint32_t c = (&h[0][0])[i];
@@ -147,7 +168,8 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
 }
 
 struct Stretch {  // per image: lo and denominator per channel, for one or two chained stretches
-    float lo1[3], den1[3], lo2[3], den2[3];
+    StretchDiv d1[3], d2[3];
+    float lo1[3], lo2[3];
     int two;
     __device__ __forceinline__ void load(const float *pct, int b, int stride, float eps, int two_)
     {
@@ -156,15 +178,23 @@ struct Stretch {  // per image: lo and denominator per channel, for one or two c
         for (int c = 0; c < 3; ++c) {
             const float *p = pct + (size_t)(b * 3 + c) * stride;
             lo1[c] = p[0];
-            den1[c] = (p[1] - p[0]) + eps;
+            d1[c].set((p[1] - p[0]) + eps);
             lo2[c] = two ? p[2] : 0.f;
-            den2[c] = two ? (p[3] - p[2]) + eps : 1.f;
+            d2[c].set(two ? (p[3] - p[2]) + eps : 1.f);
         }
     }
+    // for results that are quantised to a byte right away
     __device__ __forceinline__ float apply(float v, int c) const
     {
-        v = clip01((v - lo1[c]) / den1[c]);
-        if (two) v = clip01((v - lo2[c]) / den2[c]);
+        v = clip01(d1[c].quot_unit(v - lo1[c]));
+        if (two) v = clip01(d2[c].quot_unit(v - lo2[c]));
+        return v;
+    }
+    // for results that are kept as float32
+    __device__ __forceinline__ float apply_exact(float v, int c) const
+    {
+        v = clip01(d1[c].quot(v - lo1[c]));
+        if (two) v = clip01(d2[c].quot(v - lo2[c]));
         return v;
     }
 };
@@ -206,8 +236,12 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     __syncthreads();
     const int npx = g.H * g.W;
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
-    RestoreImg R;
-    if (SRC) R.init(src, b, (size_t)npx);
+    __shared__ float dtab[SRC ? 768 : 1];
+    RestoreImgT<true> R;
+    if (SRC) {
+        R.init(src, b, (size_t)npx, dtab);
+        __syncthreads();
+    }
     uint8_t *labimg = lab + (size_t)b * npx * 3;
     const int ty = tile / g.tx, txi = tile % g.tx;
     const int area = g.tw * g.th;
@@ -476,7 +510,7 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
         const size_t o = ((size_t)b * npx + p) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float y = S.apply(r[(size_t)c * npx + p], c);
+            float y = S.apply_exact(r[(size_t)c * npx + p], c);
             if (gamma_mode == 1) y = pow_f32(y, gexp);
             else if (gamma_mode == 2) y = clip01(pow_f32(y, gexp));
             if (out_u8) out_u8[o + c] = (uint8_t)quant_u8(y);

@@ -27,17 +27,18 @@ __global__ void __launch_bounds__(256) k_stretch_apply(const float *__restrict__
                                                        float *__restrict__ out)
 {
     const int b = blockIdx.y;
-    float lo[3], den[3];
+    float lo[3];
+    StretchDiv den[3];  // (devutil.h: the division's own operation sequence with the reciprocal kept)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         lo[c] = pct[(b * 3 + c) * pct_stride + lo_idx];
-        den[c] = (pct[(b * 3 + c) * pct_stride + hi_idx] - lo[c]) + eps;
+        den[c].set((pct[(b * 3 + c) * pct_stride + hi_idx] - lo[c]) + eps);
     }
     const size_t base = (size_t)b * npx * 3;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = (img[base + (size_t)p * 3 + c] - lo[c]) / den[c];
+            const float v = den[c].quot(img[base + (size_t)p * 3 + c] - lo[c]);
             out[base + (size_t)p * 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
         }
     }

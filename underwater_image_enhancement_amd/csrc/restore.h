@@ -11,13 +11,18 @@ namespace uwie {
 typedef uint32_t __attribute__((aligned(1))) u32_any;
 typedef double2 __attribute__((aligned(8))) double2_a8;
 
-struct RestoreImg {  // per image, in registers
+// TAB: the float32 differences I - A of the 3 x 256 possible bytes come from a table in LDS (3 KB, filled by the
+// block in init(): the caller synchronises before the first use) instead of five operations per value.
+template <bool TAB>
+struct RestoreImgT {  // per image, in registers
     const uint8_t *img;
     const double *t;
+    const float *tab;
     float a[3];
     bool att[3];
-    __device__ __forceinline__ void init(const RestoreSrc &S, int b, size_t npx)
+    __device__ __forceinline__ void init(const RestoreSrc &S, int b, size_t npx, float *lds_tab = nullptr)
     {
+        tab = lds_tab;
         const int k = S.kind ? S.kind[b] : 0;
         img = S.in + (size_t)b * npx * 3;
         t = S.t + (size_t)b * npx;
@@ -26,10 +31,18 @@ struct RestoreImg {  // per image, in registers
             a[c] = S.A[b * 3 + c];
             att[c] = px_atten(k, c);
         }
+        if (TAB) {
+            for (int i = threadIdx.x; i < 768; i += blockDim.x) {
+                const int c = i >> 8;
+                const float x = px_norm_fast((uint32_t)(i & 255));
+                lds_tab[i] = ((c == 0 ? att[0] : c == 1 ? att[1] : att[2]) ? x * 0.85f : x) - (c == 0 ? a[0] : c == 1 ? a[1] : a[2]);
+            }
+        }
     }
     // px_norm_fast(u) == u / 255.0f for every byte (tests/test_cabi.py), so this is px_val() without the division
     __device__ __forceinline__ float diff(uint32_t u, int c) const
     {
+        if (TAB) return tab[c * 256 + u];
         const float x = px_norm_fast(u);
         return (att[c] ? x * 0.85f : x) - a[c];
     }
@@ -105,5 +118,7 @@ struct RestoreImg {  // per image, in registers
         }
     }
 };
+
+using RestoreImg = RestoreImgT<false>;
 
 }  // namespace uwie
