@@ -31,7 +31,7 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 // COLLECT (with LIN): values whose digit lies in one of the plane's two predicted windows (LinState::wlo, wspan) are
 // filed into the window's list on the way: staged in LDS, moved out in batches (a block reserves list space once per
 // batch and window).
-constexpr int kWinStage = 128;
+constexpr int kWinStage = 256;
 template <bool LIN, bool COLLECT>
 __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist,
@@ -42,7 +42,6 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     constexpr int NS = COLLECT ? 6 : 1, SN = COLLECT ? kWinStage : 1;
     __shared__ uint32_t h[3][NB];
     __shared__ float stg[NS][SN];
-    __shared__ float dtab[768];
     __shared__ uint32_t scount[NS], sbase[NS];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
@@ -50,49 +49,46 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
         if (tid < NS) scount[tid] = 0;
     }
-    RestoreImgT<true> R;
-    R.init(S, b, (size_t)npx, dtab);
+    RestoreImgT<false> R;
+    R.init(S, b, (size_t)npx);
     __syncthreads();
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
-    uint32_t wlo[3][2], wspan[3][2];
+    // COLLECT: the top two bits of a bin's LDS counter say which window (1, 2) the bin belongs to, so the histogram
+    // atomic's return value tells whether the value is a candidate: no separate window test per value
+    constexpr uint32_t kCntMask = 0x3fffffffu;
+    if (COLLECT) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            wlo[c][w] = COLLECT ? lin[3 * b + c].wlo[w] : kLinNoWin;
-            wspan[c][w] = COLLECT ? lin[3 * b + c].wspan[w] : 0;
-        }
+            for (int w = 0; w < 2; ++w) {
+                const uint32_t lo = lin[3 * b + c].wlo[w], span = lin[3 * b + c].wspan[w];
+                if (lo != kLinNoWin)
+                    for (uint32_t i = tid; i <= span; i += 256) h[c][lo + i] = (uint32_t)(w + 1) << 30;
+            }
+        __syncthreads();
+    }
     // Key digits (sign, exponent, 2 mantissa bits) take a dozen values on a whole frame, so plain LDS atomics would
     // serialise 64 deep: each thread counts runs of equal digits in registers and touches LDS only when the digit
     // changes.  Linear digits spread over thousands of bins and change from pixel to pixel, so they go straight to LDS,
     // except the two saturated bins (clipped 0 and 1 fill whole regions), which are counted in registers.
     uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0}, sat0[3] = {0, 0, 0}, sat1[3] = {0, 0, 0};
-    auto bump = [&](int c, uint32_t d, float x) {
-        if (LIN) {
-            sat0[c] += d == 0;
-            sat1[c] += d == (uint32_t)kLinBins - 1;
-            if (d - 1 < (uint32_t)kLinBins - 2) atomicAdd(&h[c][d], 1u);
-        } else {
-            if (d != cur[c]) {
-                if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
-                cur[c] = d;
-                run[c] = 0;
-            }
-            ++run[c];
+    auto bump = [&](int c, uint32_t d) {
+        if (d != cur[c]) {
+            if (run[c]) atomicAdd(&h[c][cur[c]], run[c]);
+            cur[c] = d;
+            run[c] = 0;
         }
-        if (COLLECT) {
-            const bool ia = d - wlo[c][0] <= wspan[c][0], ib = d - wlo[c][1] <= wspan[c][1];  // (disjoint)
-            if (ia || ib) {
-                const int j = c * 2 + (ia ? 0 : 1);
-                const uint32_t pos = atomicAdd(&scount[j], 1u);
-                if (pos < (uint32_t)SN) {
-                    stg[j][pos] = x;
-                } else {  // a burst (a smooth region at the percentile's level): straight to the list
-                    const uint32_t idx = atomicAdd(&lin[3 * b + c].gcount[j & 1], 1u);
-                    if (idx < cap) lists[((size_t)(3 * b + c) * kLinLists + (j & 1)) * cap + idx] = x;
-                }
-            }
+        ++run[c];
+    };
+    auto file = [&](int c, int w, float x) {  // x is a candidate of window w of channel c
+        const int j = c * 2 + w;
+        const uint32_t pos = atomicAdd(&scount[j], 1u);
+        if (pos < (uint32_t)SN) {
+            stg[j][pos] = x;
+        } else {  // a burst (a smooth region at the percentile's level): straight to the list
+            const uint32_t idx = atomicAdd(&lin[3 * b + c].gcount[w], 1u);
+            if (idx < cap) lists[((size_t)(3 * b + c) * kLinLists + w) * cap + idx] = x;
         }
     };
     auto flush = [&](bool force) {  // all threads of the block call
@@ -122,12 +118,33 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         if (n > 0) {
             float r[3][4];
             R.four(p, n, r);
-            if (ghist) {
+            if (ghist && LIN) {
+                // all twelve histogram atomics first, their return values (window flags) afterwards: one LDS round trip
+                uint32_t old[3][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // r is clipped to [0, 1]: lin_digit(x) == (uint)(x * 2048) + (x > 0)
+                        const uint32_t d = (uint32_t)(r[c][i] * 2048.0f) + (r[c][i] > 0.0f ? 1u : 0u);
+                        const bool live = i < n;
+                        sat0[c] += live && d == 0;
+                        sat1[c] += live && d == (uint32_t)kLinBins - 1;
+                        old[c][i] = live && d - 1 < (uint32_t)kLinBins - 2 ? atomicAdd(&h[c][d], 1u) : 0u;
+                    }
+                if (COLLECT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (old[c][i] >> 30) file(c, (int)(old[c][i] >> 30) - 1, r[c][i]);
+                }
+            } else if (ghist) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < n) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) bump(c, LIN ? lin_digit(r[c][i]) : f32_key(r[c][i]) >> 21, r[c][i]);
+                        for (int c = 0; c < 3; ++c) bump(c, f32_key(r[c][i]) >> 21);
                     }
                 }
             }
@@ -162,7 +179,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     }
     __syncthreads();
     for (int i = tid; i < 3 * NB; i += 256) {
-        const uint32_t c = (&h[0][0])[i];
+        const uint32_t c = (&h[0][0])[i] & (COLLECT ? kCntMask : 0xffffffffu);
         if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / NB) * kSelGroupStride + (i % NB)], c);
     }
 }
