@@ -88,14 +88,18 @@ struct RestoreImgT {  // per image, in registers
 #pragma unroll
             for (int i = 0; i < 4; ++i) tv[i] = i < n ? t[p + i] : 1.0;
         }
+        // one branch per group, so that the four pixels' straight-line fast paths can be interleaved
+        if (recip_ok(tv[0]) && recip_ok(tv[1]) && recip_ok(tv[2]) && recip_ok(tv[3])) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (recip_ok(tv[i])) {
+            for (int i = 0; i < 4; ++i) {
                 const double y = recip(tv[i]);
                 r[0][i] = one_fast(v.r[i], 0, tv[i], y);
                 r[1][i] = one_fast(v.g[i], 1, tv[i], y);
                 r[2][i] = one_fast(v.b[i], 2, tv[i], y);
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
                 r[0][i] = one(v.r[i], 0, tv[i]);
                 r[1][i] = one(v.g[i], 1, tv[i]);
                 r[2][i] = one(v.b[i], 2, tv[i]);
