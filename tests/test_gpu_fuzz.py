@@ -1,0 +1,67 @@
+"""Randomised differential test of the enhancement entry point against the oracle: many small frames of random size and
+content (noise, gradients, flat regions with sparse detail, saturated regions, colour casts, ragged sizes), every
+six_stadigy strategy.  The contract is the same as in test_gpu_enhance.py (<= 1 LSB, the guided filter's tolerance); in
+practice every byte is equal, and the test says so when it is not."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uw():
+    import underwater_image_enhancement_amd as uw
+
+    return uw
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import uwie_oracle
+
+    return uwie_oracle
+
+
+def random_frame(rng):
+    H, W = int(rng.integers(16, 260)), int(rng.integers(16, 340))
+    kind = rng.integers(0, 6)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    if kind == 0:  # uniform noise
+        f = rng.integers(0, 256, (H, W, 3)).astype(np.float64)
+    elif kind == 1:  # smooth gradients + noise
+        f = np.stack([rng.uniform(0, 200) + rng.uniform(-0.5, 0.5) * xx + rng.uniform(-0.5, 0.5) * yy for _ in range(3)], -1)
+        f += rng.normal(0, rng.uniform(1, 20), f.shape)
+    elif kind == 2:  # flat colour with sparse detail: heavy bins
+        f = np.empty((H, W, 3))
+        f[:] = rng.integers(20, 236, 3)
+        m = rng.random((H, W)) < 0.03
+        f[m] = rng.integers(0, 256, (int(m.sum()), 3))
+    elif kind == 3:  # saturated regions: clipped restored values
+        f = rng.normal(128, 90, (H, W, 3))
+        f[: H // 3] = 255
+        f[-H // 4:, : W // 2] = 0
+    elif kind == 4:  # low-contrast haze with a cast
+        f = rng.normal(150, 8, (H, W, 3)) * np.array([0.5, 1.0, 0.95])
+    else:  # blobs: piecewise smooth
+        f = np.zeros((H, W, 3))
+        for _ in range(6):
+            cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(5, 80)
+            f += np.exp(-(((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r)))[..., None] * rng.uniform(20, 120, 3)
+        f += rng.normal(0, 3, f.shape)
+    gains = (1.0, 1.0, 1.0) if rng.random() < 0.4 else rng.uniform(0.4, 1.0, 3)
+    return np.clip(f * gains, 0, 255).astype(np.uint8)
+
+
+def test_random_frames_every_strategy(uw, orc):
+    rng = np.random.default_rng(20260704)
+    cases = differing = 0
+    for i in range(90):
+        u8 = random_frame(rng)
+        for k in ((1, 2, 3) if i % 3 else (1, 2, 3, 4, 5, 6)):
+            got, want = uw.enhance(u8, strategy=k), orc.enhance_u8(u8, k)
+            assert got.shape == want.shape and got.dtype == np.uint8
+            d = np.abs(got.astype(int) - want.astype(int))
+            assert d.max() <= 1, f"frame {i} {u8.shape} strategy {k}: max |delta| = {d.max()} LSB"
+            cases += 1
+            differing += int(np.count_nonzero(d))
+    assert differing == 0, f"{differing} bytes differ by 1 LSB over {cases} cases (allowed by the contract, but unexpected)"
