@@ -438,8 +438,28 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     constexpr int BASE = 1 << 14;
     const int gpr = (cx1 - cx0 + 3) / 4, total = (cy1 - cy0) * gpr;  // 4-pixel groups per row, in the block
     const uint32_t gmagic = (uint32_t)(((1ull << 32) + gpr - 1) / gpr);
-    for (int gi = tid; gi < total; gi += 256) {
-        const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr (gi < 2^32 / gpr)
+    struct Cols {  // per 4-pixel group: LUT window columns and blend weights of its pixels (they depend on x only)
+        int c1[4], c2[4];
+        float xa[4], xa1[4];
+    };
+    auto cols_of = [&](int x0) {
+        Cols C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = min(x0 + i, g.W - 1);
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf);
+            int tx2 = tx1 + 1;
+            C.xa[i] = txf - (float)tx1;
+            C.xa1[i] = 1.0f - C.xa[i];
+            tx1 = max(tx1, 0);
+            tx2 = min(tx2, g.tx - 1);
+            C.c1[i] = min(max(tx1 - wx0, 0), 3);
+            C.c2[i] = min(max(tx2 - wx0, 0), 3);
+        }
+        return C;
+    };
+    auto group = [&](int row, int xg, const Cols &C) {
         const int y = cy0 + row, x0 = cx0 + 4 * xg, n = min(4, cx1 - x0);
         const size_t pix = ((size_t)b * g.H + y) * g.W + x0;
         Px4 in4;  // r,g,b fields hold L,a,b
@@ -463,14 +483,8 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         uint32_t o0[4], o1[4], o2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int x = min(x0 + i, g.W - 1);
-            const float txf = (float)x * inv_tw - 0.5f;
-            int tx1 = (int)floorf(txf);
-            int tx2 = tx1 + 1;
-            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
-            tx1 = max(tx1, 0);
-            tx2 = min(tx2, g.tx - 1);
-            const int c1 = min(max(tx1 - wx0, 0), 3), c2 = min(max(tx2 - wx0, 0), 3);
+            const int c1 = C.c1[i], c2 = C.c2[i];
+            const float xa = C.xa[i], xa1 = C.xa1[i];
             const int v = in4.r[i], aa = in4.g[i], bb = in4.b[i];
             const float l11 = (float)s_lut[r1 + c1][v], l12 = (float)s_lut[r1 + c2][v];
             const float l21 = (float)s_lut[r2 + c1][v], l22 = (float)s_lut[r2 + c2][v];
@@ -510,6 +524,20 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
             } else {
                 store_px4(out_u8 + o, o0, o1, o2, n, false);
             }
+        }
+    };
+    const int rows = cy1 - cy0, rstep = 256 / max(gpr, 1);
+    if (gpr <= 256 && rstep * gpr * 8 >= 256 * 7) {
+        // a thread keeps its 4-pixel column group and walks down the rows: the column terms are computed once
+        if (tid < rstep * gpr) {
+            const int xg = tid % gpr;
+            const Cols C = cols_of(cx0 + 4 * xg);
+            for (int row = tid / gpr; row < rows; row += rstep) group(row, xg, C);
+        }
+    } else {
+        for (int gi = tid; gi < total; gi += 256) {
+            const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr (gi < 2^32 / gpr)
+            group(row, xg, cols_of(cx0 + 4 * xg));
         }
     }
 }
