@@ -37,6 +37,7 @@ struct CannyBufs {
     uint32_t *ncand;   // their lengths, [tile][4]
     uint2 *roots;      // tile-local component roots, same slots: {pixel index of the root, size | strong pixels << 16}
     uint32_t *nroot;   // their counts, [tile][4]
+    uint32_t *nborder; // candidates on the tile's left / right column or bottom row: they lead their list, [tile][4]
     int tiles;         // tiles per region in this launch
 };
 
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     if (tid == 0) s_total = 0;  // (the barrier after the tile fill orders this before the atomics)
     const size_t sub = ((size_t)blockIdx.y * bufs.tiles + blockIdx.x) * 4 + (tid >> 6);  // this wavefront's list
     if (ty0 >= r.rows || tx0 >= r.cols) {
-        if ((tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = 0;
+        if ((tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = bufs.nborder[sub] = 0;
         return;
     }
     const size_t base = (size_t)r.img * H * W;
@@ -254,14 +255,21 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             nr += !dense || (int)myroot[k] == li;
         }
     }
-    const uint32_t both = wave_incl_scan_u32(ncand | (nr << 16));  // one scan for both list offsets (<= 512 each)
-    const uint32_t incl = both & 0xffffu, rincl = both >> 16;
+    // candidates that can have a neighbour in another tile (left / right column, bottom row) lead the list: the
+    // cross-tile union walks only them
+    const uint32_t bordermask = keepmask & ((cg == 0 ? 0x11u : 0u) | (cg == 15 ? 0x88u : 0u) | (rp == 15 ? 0xf0u : 0u));
+    const uint32_t nb = __popc(bordermask);
+    const uint32_t all3 = wave_incl_scan_u32(ncand | (nr << 10) | (nb << 20));  // one scan for the three offsets (<= 512 each)
+    const uint32_t incl = all3 & 0x3ffu, rincl = (all3 >> 10) & 0x3ffu, bincl = all3 >> 20;
+    const uint32_t total_b = __shfl(bincl, 63);
     if ((tid & 63) == 63) {
         bufs.ncand[sub] = incl;
         bufs.nroot[sub] = rincl;
+        bufs.nborder[sub] = bincl;
     }
     {
-        uint32_t *dst = bufs.cand + sub * 512 + (incl - ncand);
+        uint32_t *dst_b = bufs.cand + sub * 512 + (bincl - nb);
+        uint32_t *dst_i = bufs.cand + sub * 512 + total_b + ((incl - bincl) - (ncand - nb));
         int k = 0;
         for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
             const int b = __ffs(km) - 1;
@@ -269,7 +277,8 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
             const int proot = (r.y0 + ty0 + root / kCT_W) * W + r.x0 + tx0 + root % kCT_W;
             bufs.label[base + p] = proot;
-            *dst++ = (uint32_t)p;
+            if ((bordermask >> b) & 1) *dst_b++ = (uint32_t)p;
+            else *dst_i++ = (uint32_t)p;
         }
     }
     if (nr) {
@@ -352,21 +361,39 @@ __device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
 
 __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
+    // On a dense map a tile is a handful of components and its ~200 border candidates ask for the same few unions
+    // (tile root, neighbour's tile root) over and over, all of them chasing the same hot roots through L2.  A union is
+    // idempotent, so a pair that is already in this block's small LDS table (someone has taken it) is skipped; a
+    // collision only costs a repeated union.
+    __shared__ unsigned long long s_seen[512];
+    for (int i = threadIdx.x; i < 512; i += 256) s_seen[i] = ~0ull;
+    __syncthreads();
     const Region r = regs[blockIdx.y];
     const size_t base = (size_t)r.img * H * W;
     const uint8_t *cm = bufs.cmap + base;
     int32_t *L = bufs.label + base;
-    for_candidates(bufs, [&](int p) {
+    auto link = [&](int p, int q) {
+        // the labels written by k_canny_gradnms are the tile-local roots: start from them (any ancestor will do)
+        int a = ld_label(L, p), b = ld_label(L, q);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
+        const uint32_t slot = ((uint32_t)a * 0x9e3779b1u ^ (uint32_t)b * 0x85ebca6bu) >> 23;
+        if (atomicExch(&s_seen[slot], key) == key) return;
+        uf_union(L, a, b);
+    };
+    for_list(bufs.nborder, bufs.tiles, [&](size_t pos) {
         // links inside a tile were made in LDS by k_canny_gradnms: only pairs that straddle a tile border are left
+        const int p = (int)bufs.cand[pos];
         const int y = p / W, x = p - y * W;
         const int lx = (x - r.x0) % kCT_W, ly = (y - r.y0) % kCT_H;
         const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
         const bool xr = lx == kCT_W - 1, xl = lx == 0, yd = ly == kCT_H - 1;
-        if (right && xr && cm[p + 1] != 1) uf_union(L, p, p + 1);
+        if (right && xr && cm[p + 1] != 1) link(p, p + 1);
         if (down) {
-            if (left && (yd || xl) && cm[p + W - 1] != 1) uf_union(L, p, p + W - 1);
-            if (yd && cm[p + W] != 1) uf_union(L, p, p + W);
-            if (right && (yd || xr) && cm[p + W + 1] != 1) uf_union(L, p, p + W + 1);
+            if (left && (yd || xl) && cm[p + W - 1] != 1) link(p, p + W - 1);
+            if (yd && cm[p + W] != 1) link(p, p + W);
+            if (right && (yd || xr) && cm[p + W + 1] != 1) link(p, p + W + 1);
         }
     });
 }
@@ -446,6 +473,7 @@ CannyBufs carve_canny(Carver &c, Shape s)
     b.ncand = c.take<uint32_t>(canny_list_tiles(s) * 4);
     b.roots = c.take<uint2>(canny_list_tiles(s) * 2048);
     b.nroot = c.take<uint32_t>(canny_list_tiles(s) * 4);
+    b.nborder = c.take<uint32_t>(canny_list_tiles(s) * 4);
     return b;
 }
 
