@@ -172,6 +172,13 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
     // non-maximum suppression, branch-free: the two neighbours along the gradient direction are selected, not branched on
     uint32_t cls[2] = {0x01010101u, 0x01010101u}, keepmask = 0;
+    // a wavefront whose 8 x 64 pixels all stay at or below the low threshold (smooth water) has nothing to suppress
+    int hot = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hot = max(hot, mag[i + 1][j + 1]);
+    if (__ballot(hot > low)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
                 cls[i] = (cls[i] & ~(0xffu << (8 * j))) | ((m > high ? 2u : 0u) << (8 * j));
             }
         }
+    }
     }
     const uint32_t ncand = __popc(keepmask);
     // map bytes: one (unaligned) dword per row when the 4 pixels exist, else byte by byte
