@@ -46,7 +46,7 @@ struct WaveCfg {
     static constexpr int NLp = NL + 1;
     static constexpr int SW = (64 + M + 2) & ~1;          // staging line: 64 lanes + the look-ahead of the last lane
     static constexpr int ring_bytes = RC * 2 * NLp * 16;
-    static constexpr int region_doubles = 4 * SW;         // 2 planes x {P, slot-0 value}
+    static constexpr int region_doubles = 6 * SW;         // up to 3 planes x {P, slot-0 value}
     // two staging regions (alternating) unless that costs a resident wavefront per CU
     // staging regions: 1 measured faster than 2 alternating ones (6.6 vs 7.4 ms at 4K x 64, k = 15): LDS bytes per
     // wavefront decide how many strips a CU holds (five up to 31.5 KB each, four beyond: measured), and that matters
@@ -102,6 +102,64 @@ __device__ __forceinline__ void window_sums2(double *reg, int lane, const double
         } else {                // K = 2M:   o0 = P[l..l+M-1];            o1 = v1 + P[l+1..l+M-1] + v0[l+M]
             o[p][0] = P[p] + mid;
             o[p][1] = (v[p][1] + mid) + f0;
+        }
+    }
+    if constexpr (C::NREG == 1) wave_sync();
+}
+
+// The first box filter's three planes in ONE staging round trip: the guide is a byte, so the window sums of g and g*g
+// are exact integers (<= 225 * 255^2 < 2^24) and travel packed in one 64-bit word (g in the high half, g*g in the low
+// half: the halves never carry into each other); p and g*p are float64.  Same outputs as window_sums2.
+template <int K, int NREG>
+__device__ __forceinline__ void window_sums3(double *reg, int lane, const unsigned long long (&vi)[2], const double (&v)[2][2],
+                                             unsigned long long (&oi)[2], double (&o)[2][2])
+{
+    using C = WaveCfg<K, NREG>;
+    constexpr int M = C::M, SW = C::SW;
+    unsigned long long *regi = reinterpret_cast<unsigned long long *>(reg) + 4 * SW;
+    double P[2];
+    const unsigned long long Pi = vi[0] + vi[1];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        P[p] = v[p][0] + v[p][1];
+        reg[(2 * p) * SW + lane] = P[p];
+        reg[(2 * p + 1) * SW + lane] = v[p][0];
+    }
+    regi[lane] = Pi;
+    regi[SW + lane] = vi[0];
+    wave_sync();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const double *ps = reg + (2 * p) * SW + lane;
+        double mid0 = ps[1], mid1 = ps[2];  // sum of P over lanes l+1 .. l+M-1, two chains
+#pragma unroll
+        for (int d = 3; d < M; d += 2) mid0 += ps[d];
+#pragma unroll
+        for (int d = 4; d < M; d += 2) mid1 += ps[d];
+        const double mid = mid0 + mid1;
+        const double f0 = ps[SW + M];  // slot 2(l+M)
+        if constexpr (K & 1) {
+            o[p][0] = (P[p] + mid) + f0;
+            o[p][1] = (v[p][1] + mid) + ps[M];
+        } else {
+            o[p][0] = P[p] + mid;
+            o[p][1] = (v[p][1] + mid) + f0;
+        }
+    }
+    {
+        const unsigned long long *ps = regi + lane;
+        unsigned long long mid0 = ps[1], mid1 = ps[2];
+#pragma unroll
+        for (int d = 3; d < M; d += 2) mid0 += ps[d];
+#pragma unroll
+        for (int d = 4; d < M; d += 2) mid1 += ps[d];
+        const unsigned long long mid = mid0 + mid1, f0 = ps[SW + M];
+        if constexpr (K & 1) {
+            oi[0] = (Pi + mid) + f0;
+            oi[1] = (vi[1] + mid) + ps[M];
+        } else {
+            oi[0] = Pi + mid;
+            oi[1] = (vi[1] + mid) + f0;
         }
     }
     if constexpr (C::NREG == 1) wave_sync();
@@ -216,21 +274,24 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
     };
 
     // ---- prologue: vertical sums of the band's first a/b row by direct summation
-    double V1[4][2], V2[2][2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) V1[p][0] = V1[p][1] = 0.0;
+    double V1[2][2], V2[2][2];   // V1: vertical sums of p and g*p (g = the guide byte; I = g/255 is applied to the window sums)
+    uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};  // vertical sums of g and g*g: exact integers
+    V1[0][0] = V1[0][1] = V1[1][0] = V1[1][1] = 0.0;
     V2[0][0] = V2[0][1] = V2[1][0] = V2[1][1] = 0.0;
     for (int j = 0; j < K; ++j) {
         const size_t row = (size_t)reflect_clamp(r_lo - a + j, H) * W;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double I = u8_over_255(gimg[row + craw[c]]), p = (double)timg[row + craw[c]];
-            V1[0][c] += I;
-            V1[1][c] += p;
-            V1[2][c] += I * p;
-            V1[3][c] += I * I;
+            const uint32_t gq = gimg[row + craw[c]];
+            const double p = (double)timg[row + craw[c]];
+            Sg[c] += gq;
+            Sgg[c] += gq * gq;
+            V1[0][c] += p;
+            V1[1][c] += (double)gq * p;
         }
     }
+    // mean_I = sum(g) / (255 K^2), corr_I = sum(g*g) / (255^2 K^2), corr_Ip = sum(g*p) / (255 K^2)
+    const double scale_g = scale * (1.0 / 255.0), scale_gg = scale * (1.0 / (255.0 * 255.0));
 
     int wslot = r_lo % RC;                        // ring slot of a/b row r1
     int pslot = wslot == 0 ? RC - 1 : wslot - 1;  // ring slot of a/b row r1 - 1
@@ -262,24 +323,26 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
             if (STEADY || r1 != r_lo) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double Ie = u8_over_255(in.ge[c]), pe = (double)in.te[c];
-                    const double Il = u8_over_255(in.gl[c]), pl = (double)in.tl[c];
-                    V1[0][c] += Ie - Il;
-                    V1[1][c] += pe - pl;
-                    V1[2][c] += Ie * pe - Il * pl;
-                    V1[3][c] += Ie * Ie - Il * Il;
+                    const double pe = (double)in.te[c], pl = (double)in.tl[c];
+                    Sg[c] += in.ge[c] - in.gl[c];
+                    Sgg[c] += in.ge[c] * in.ge[c] - in.gl[c] * in.gl[c];
+                    V1[0][c] += pe - pl;
+                    V1[1][c] += (double)in.ge[c] * pe - (double)in.gl[c] * pl;
                 }
             }
             double m[4][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double vin[2][2] = {{V1[2 * h][0], V1[2 * h][1]}, {V1[2 * h + 1][0], V1[2 * h + 1][1]}};
+            {
+                const unsigned long long vi[2] = {((unsigned long long)Sg[0] << 32) | Sgg[0], ((unsigned long long)Sg[1] << 32) | Sgg[1]};
+                const double vin[2][2] = {{V1[0][0], V1[0][1]}, {V1[1][0], V1[1][1]}};
+                unsigned long long oi[2];
                 double o[2][2];
-                window_sums2<K, NREG>(region(), lane, vin, o);
+                window_sums3<K, NREG>(region(), lane, vi, vin, oi, o);
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    m[2 * h + p][0] = o[p][0] * scale;
-                    m[2 * h + p][1] = o[p][1] * scale;
+                for (int c = 0; c < 2; ++c) {
+                    m[0][c] = (double)(uint32_t)(oi[c] >> 32) * scale_g;
+                    m[1][c] = o[0][c] * scale;
+                    m[2][c] = o[1][c] * scale_g;
+                    m[3][c] = (double)(uint32_t)oi[c] * scale_gg;
                 }
             }
 #pragma unroll
