@@ -209,9 +209,18 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
     UWIE_TRY(stage_guided(P, s, p, st));
     SelectPlan plan;
     const double q[2] = {p->L_low, p->L_high};
-    UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
-    UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st));
-    UWIE_TRY(select_run64(plan, P.F64, 1, s, true, st));
+    // the recovered image is clipped to [0, 1]: linear first digit, one collecting sweep (select_lin_*64);
+    // UWIE_SELECT_GENERIC=1 keeps the six-digit key sweeps
+    const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    if (env_generic && atoi(env_generic) == 1) {
+        UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
+        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st));
+        UWIE_TRY(select_run64(plan, P.F64, 1, s, true, st));
+    } else {
+        UWIE_TRY(select_lin_begin64(s, q, 2, P.scratch, st, &plan));
+        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st, true));
+        UWIE_TRY(select_lin_run64(plan, P.F64, s, st));
+    }
     UWIE_TRY(select_lerp64(plan, s, P.pct64, st));
     return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st);
 }

@@ -220,6 +220,13 @@ __host__ __device__ inline uint32_t lin_digit(float x)
     const uint32_t d = (uint32_t)(x * 2048.0f);  // exact product, truncation: monotone in x
     return 1 + (d > 2047u ? 2047u : d);
 }
+__host__ __device__ inline uint32_t lin_digit(double x)  // the same split for the float64 planes of the ES surface
+{
+    if (!(x > 0.0)) return 0;
+    if (x >= 1.0) return kLinBins - 1;
+    const uint32_t d = (uint32_t)(x * 2048.0);
+    return 1 + (d > 2047u ? 2047u : d);
+}
 // Per (image, channel) state of the linear-digit selection.  With a prediction (select_lin_begin(..., predict)) the
 // producer already files the elements of two windows of bins, each around the predicted position of a percentile's
 // ranks, into one list per window during its own sweep; the scan then checks the prediction against the exact
@@ -242,6 +249,9 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
 // src != nullptr: the values are recomputed from *src; d_planar is then only written (and read back) for planes that
 // fall back to the generic sweeps
 int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc *src = nullptr);
+// float64 planes (ES surface): linear first digit by the producer, one collecting sweep, finish on the lists
+int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+int select_lin_run64(const SelectPlan &plan, const double *d_planar, Shape s, hipStream_t st);
 int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
 int select_lerp(const SelectPlan &plan, Shape s, float *d_out, hipStream_t st);                     // [B][3][nq]
@@ -278,7 +288,7 @@ int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride,
 // ES surface (float64): recover_image (ES:237-249) -> planar float64 + first select digit; color_enhancement
 // (ES:269-270, eps 1e-10) [-> gamma_correction (ES:284-285)] -> (y*255).astype(u8) (main.py:155) / float32 copy
 int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
-                                 uint32_t *d_ghist, hipStream_t st);
+                                 uint32_t *d_ghist, hipStream_t st, bool linear = false);
 int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
                         uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
 

@@ -566,13 +566,16 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
 
 // ---- ES surface, float64
 // recovered = clip((img - A) / t + A, 0, 1): float32 difference, float64 quotient/sum/result (ES:247-248)
+// LIN: the histogram is over lin_digit() (select_lin_*64), else over the top 11 key bits
+template <bool LIN>
 __global__ void __launch_bounds__(256) k_recover64_planar_hist(const uint8_t *__restrict__ in, const float *__restrict__ A,
                                                                const double *__restrict__ t, int npx,
                                                                double *__restrict__ planar, uint32_t *__restrict__ ghist)
 {
-    __shared__ uint32_t h[3][2048];
+    constexpr int NB = LIN ? 2052 : 2048;
+    __shared__ uint32_t h[3][NB];
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < 3 * 2048; i += 256) (&h[0][0])[i] = 0;
+    for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
     const uint8_t *img = in + (size_t)b * npx * 3;
@@ -586,14 +589,14 @@ __global__ void __launch_bounds__(256) k_recover64_planar_hist(const uint8_t *__
         o0[p] = r0;
         o1[p] = r1;
         o2[p] = r2;
-        atomicAdd(&h[0][(uint32_t)(f64_key(r0) >> 53)], 1u);
-        atomicAdd(&h[1][(uint32_t)(f64_key(r1) >> 53)], 1u);
-        atomicAdd(&h[2][(uint32_t)(f64_key(r2) >> 53)], 1u);
+        atomicAdd(&h[0][LIN ? lin_digit(r0) : (uint32_t)(f64_key(r0) >> 53)], 1u);
+        atomicAdd(&h[1][LIN ? lin_digit(r1) : (uint32_t)(f64_key(r1) >> 53)], 1u);
+        atomicAdd(&h[2][LIN ? lin_digit(r2) : (uint32_t)(f64_key(r2) >> 53)], 1u);
     }
     __syncthreads();
-    for (int i = tid; i < 3 * 2048; i += 256) {
+    for (int i = tid; i < 3 * NB; i += 256) {
         const uint32_t c = (&h[0][0])[i];
-        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / 2048) * kSelGroupStride + (i % 2048)], c);
+        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / NB) * kSelGroupStride + (i % NB)], c);
     }
 }
 
@@ -679,14 +682,18 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 }
 
 int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
-                                 uint32_t *d_ghist, hipStream_t st)
+                                 uint32_t *d_ghist, hipStream_t st, bool linear)
 {
     int nblk = 2048 / s.B;
     nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
     const int need = cdiv((long long)s.npx(), 256);
     if (nblk > need) nblk = need;
-    UWIE_LAUNCH(k_recover64_planar_hist, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar,
-                d_ghist);
+    const auto k_recover64_hist_lin = k_recover64_planar_hist<true>;  // (names as the profiler reports them)
+    const auto k_recover64_hist_key = k_recover64_planar_hist<false>;
+    if (linear)
+        UWIE_LAUNCH(k_recover64_hist_lin, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar, d_ghist);
+    else
+        UWIE_LAUNCH(k_recover64_hist_key, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar, d_ghist);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -505,8 +505,9 @@ __global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, 
 // one block per (image, channel): the bin of every rank from the producer's histogram; ranks in the bins of exact
 // 0 / exact 1 are answered here.  A plane all of whose other queries fall into the predicted windows is done with
 // collecting (ngroups = 0, gid = the window's list); otherwise its queries are grouped by bin for the collecting sweep.
+template <typename V>
 __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
-                                                  RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags,
+                                                  RankList ranks, V *__restrict__ os, uint32_t *__restrict__ flags,
                                                   uint32_t cap)
 {
     __shared__ uint32_t h[kLinBins], wsum[4], found[2], qbin[kMaxRanks], qrr[kMaxRanks];
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
             s.rr[q] = qrr[q];
             s.qbin[q] = qbin[q];
             if (qbin[q] == 0 || qbin[q] == kLinBins - 1) {  // every element of these bins is 0 resp. 1
-                os[bc * kMaxRanks + q] = qbin[q] == 0 ? 0.0f : 1.0f;
+                os[bc * kMaxRanks + q] = qbin[q] == 0 ? (V)0 : (V)1;
                 continue;
             }
             int w = -1;
@@ -559,10 +560,12 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
 
 // grid (blocks, B*3): one sweep over the plane; elements whose bin is a target bin go to that group's list.  A block
 // stages its candidates in LDS (they are ~0.5 % of the elements) and reserves list space for a batch at a time.
-__global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ vals, int n, LinState *__restrict__ st,
-                                                     float *__restrict__ lists, uint32_t cap)
+template <typename V>
+__global__ void __launch_bounds__(256) k_lin_collect(const V *__restrict__ vals, int n, LinState *__restrict__ st,
+                                                     V *__restrict__ lists, uint32_t cap)
 {
-    __shared__ float stg[kMaxRanks][kLinStage];
+    constexpr int kStage = sizeof(V) == 8 ? 256 : 512;  // 16 KB of LDS either way
+    __shared__ V stg[kMaxRanks][kStage];
     __shared__ uint32_t scount[kMaxRanks], sbase[kMaxRanks];
     const int bc = blockIdx.y, tid = threadIdx.x;
     LinState *s = st + bc;
@@ -575,12 +578,12 @@ __global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ v
     for (int g = 0; g < kMaxRanks; ++g) gd[g] = g < ng ? s->gbin[g] - 1 : kLinDone;
     if (tid < kMaxRanks) scount[tid] = 0;
     __syncthreads();
-    float *L = lists + (size_t)bc * kLinLists * cap;
-    const float *v = vals + (size_t)bc * n;
+    V *L = lists + (size_t)bc * kLinLists * cap;
+    const V *v = vals + (size_t)bc * n;
     const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
     const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
-    auto take = [&](float x, bool live) {
-        const uint32_t d = (live && x > 0.0f) ? (uint32_t)(x * 2048.0f) : 0xfffffffeu;
+    auto take = [&](V x, bool live) {
+        const uint32_t d = (live && x > (V)0) ? (uint32_t)(x * (V)2048) : 0xfffffffeu;
         uint32_t idx = kLinDone;
 #pragma unroll
         for (int g = 0; g < 4; ++g) idx = d == gd[g] ? (uint32_t)g : idx;
@@ -590,23 +593,24 @@ __global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ v
         }
         if (idx != kLinDone) {
             const uint32_t pos = atomicAdd(&scount[idx], 1u);
-            if (pos < (uint32_t)kLinStage) stg[idx][pos] = x;  // (a fuller stage is caught by flush(): the plane falls back)
+            if (pos < (uint32_t)kStage) {
+                stg[idx][pos] = x;
+            } else {  // a burst (a smooth region at the percentile's level): straight to the list
+                const uint32_t at = atomicAdd(&s->gcount[idx], 1u);
+                if (at < cap) L[(size_t)idx * cap + at] = x;
+            }
         }
     };
     // all threads of the block call: move the staged candidates to the lists when a stage is three quarters full
     auto flush = [&](bool force) {
         __syncthreads();
         bool need = force;
-        for (int g = 0; g < ng; ++g) need = need || scount[g] > (uint32_t)(kLinStage * 3 / 4);
+        for (int g = 0; g < ng; ++g) need = need || scount[g] > (uint32_t)(kStage * 3 / 4);
         if (!need) return;  // block-uniform
-        if (tid < ng) {
-            const uint32_t c = scount[tid];
-            // a stage that overflowed lost elements: make the list look overfull so that the plane takes the generic path
-            sbase[tid] = atomicAdd(&s->gcount[tid], c > (uint32_t)kLinStage ? cap + 1 : c);
-        }
+        if (tid < ng) sbase[tid] = atomicAdd(&s->gcount[tid], min(scount[tid], (uint32_t)kStage));
         __syncthreads();
         for (int g = 0; g < ng; ++g) {
-            const uint32_t c = min(scount[g], (uint32_t)kLinStage), base = sbase[g];
+            const uint32_t c = min(scount[g], (uint32_t)kStage), base = sbase[g];
             for (uint32_t i = tid; i < c; i += 256)
                 if (base + i < cap) L[(size_t)g * cap + base + i] = stg[g][i];
         }
@@ -616,25 +620,33 @@ __global__ void __launch_bounds__(256) k_lin_collect(const float *__restrict__ v
     };
     const bool vec = ((size_t)v & 15) == 0;
     const int hiv = vec ? lo + ((hi - lo) / 4) * 4 : lo;
-    constexpr int U = 4;
+    constexpr int U = sizeof(V) == 8 ? 2 : 4;  // 16-byte loads: four floats, two doubles (two per group of four)
     for (int base = lo; base < hiv; base += U * 1024) {  // block-uniform trip count
         const int i = base + tid * 4;
-        float4 raw[U];
+        V raw[U][4];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ok[u] = i + u * 1024 < hiv;
-            raw[u] = ok[u] ? *reinterpret_cast<const float4 *>(v + i + u * 1024) : make_float4(0, 0, 0, 0);
+            if constexpr (sizeof(V) == 8) {
+                const double2 lo2 = ok[u] ? *reinterpret_cast<const double2 *>(v + i + u * 1024) : make_double2(0, 0);
+                const double2 hi2 = ok[u] ? *reinterpret_cast<const double2 *>(v + i + u * 1024 + 2) : make_double2(0, 0);
+                raw[u][0] = lo2.x; raw[u][1] = lo2.y; raw[u][2] = hi2.x; raw[u][3] = hi2.y;
+            } else {
+                const float4 q = ok[u] ? *reinterpret_cast<const float4 *>(v + i + u * 1024) : make_float4(0, 0, 0, 0);
+                raw[u][0] = q.x; raw[u][1] = q.y; raw[u][2] = q.z; raw[u][3] = q.w;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            take(raw[u].x, ok[u]); take(raw[u].y, ok[u]); take(raw[u].z, ok[u]); take(raw[u].w, ok[u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take(raw[u][e], ok[u]);
         }
         flush(false);
     }
     for (int t0 = hiv; t0 < hi; t0 += 256) {
         const int j = t0 + tid;
-        take(j < hi ? v[j] : 0.0f, j < hi);
+        take(j < hi ? v[j] : (V)0, j < hi);
         flush(false);
     }
     flush(true);
@@ -673,7 +685,12 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
         for (int g = 0; g < NG; ++g) idx = d == gd[c][g] ? (uint32_t)g : idx;
         if (idx != kLinDone) {
             const uint32_t pos = atomicAdd(&scount[c * NG + idx], 1u);
-            if (pos < (uint32_t)kLinStage) stg[c * NG + idx][pos] = x;
+            if (pos < (uint32_t)kLinStage) {
+                stg[c * NG + idx][pos] = x;
+            } else {  // a burst: straight to the list
+                const uint32_t at = atomicAdd(&s[c].gcount[idx], 1u);
+                if (at < cap) lists[((size_t)(3 * b + c) * kLinLists + idx) * cap + at] = x;
+            }
         }
     };
     auto flush = [&](bool force) {  // all threads of the block call
@@ -682,8 +699,8 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
         for (int j = 0; j < 3 * NG; ++j) need = need || scount[j] > (uint32_t)(kLinStage * 3 / 4);
         if (!need) return;  // block-uniform
         if (tid < 3 * NG) {
-            const uint32_t c = scount[tid];
-            if (c) sbase[tid] = atomicAdd(&s[tid / NG].gcount[tid % NG], c > (uint32_t)kLinStage ? cap + 1 : c);
+            const uint32_t c = min(scount[tid], (uint32_t)kLinStage);
+            if (c) sbase[tid] = atomicAdd(&s[tid / NG].gcount[tid % NG], c);
         }
         __syncthreads();
         for (int j = 0; j < 3 * NG; ++j) {
@@ -717,11 +734,14 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     flush(true);
 }
 
-// one block of 1024 per (image, channel, query): the query is finished on its list by a 3-digit radix select among
-// the list's elements of the query's bin (a window's list holds neighbouring bins too)
-__global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const float *__restrict__ lists,
-                                                     uint32_t cap, float *__restrict__ os, uint32_t *__restrict__ flags)
+// one block of 1024 per (image, channel, query): the query is finished on its list by a radix select (3 digits of the
+// float32 key, 6 of the float64 key) among the list's elements of the query's bin (a window's list holds neighbouring
+// bins too)
+template <typename V>
+__global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const V *__restrict__ lists,
+                                                     uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags)
 {
+    using K = typename Traits<V>::K;
     __shared__ uint32_t h[2048], wsum[16], found[2];
     const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;  // grid (B*3, ranks)
     const LinState *s = st + bc;
@@ -732,25 +752,26 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         if (tid == 0) flags[bc] = 1;
         return;
     }
-    const float *L = lists + ((size_t)bc * kLinLists + g) * cap;
-    uint32_t prefix = 0, r = s->rr[q];
+    const V *L = lists + ((size_t)bc * kLinLists + g) * cap;
+    K prefix = 0;
+    uint32_t r = s->rr[q];
     const uint32_t tb = s->qbin[q];
-    for (int p = 0; p < 3; ++p) {
-        const int shift = Traits<float>::shift(p), bits = Traits<float>::bits(p), nbins = 1 << bits;
+    for (int p = 0; p < Traits<V>::NPASS; ++p) {
+        const int shift = Traits<V>::shift(p), bits = Traits<V>::bits(p), nbins = 1 << bits;
         for (int i = tid; i < nbins; i += 1024) h[i] = 0;
         __syncthreads();
         for (uint32_t base = 0; base < cnt; base += 4096) {  // four loads in flight per thread
-            float x[4];
+            V x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = base + u * 1024 + tid;
-                x[u] = i < cnt ? L[i] : -1.0f;  // (bin 0, never a list's target)
+                x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t key = f32_key(x[u]);
+                const K key = Traits<V>::key(x[u]);
                 if (lin_digit(x[u]) == tb && (p == 0 || (key >> (shift + bits)) == prefix))
-                    atomicAdd(&h[(key >> shift) & (nbins - 1)], 1u);
+                    atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
             }
         }
         __syncthreads();
@@ -759,7 +780,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         prefix = (prefix << bits) | d;
         r = rr;
     }
-    if (tid == 0) os[bc * kMaxRanks + q] = Traits<float>::value(prefix);
+    if (tid == 0) os[bc * kMaxRanks + q] = Traits<V>::value(prefix);
 }
 
 struct LinBufs {
@@ -773,7 +794,7 @@ LinBufs carve_lin(Carver &c, Shape s)
     const size_t nbc = (size_t)s.B * 3;
     b.lin = c.take<LinState>(nbc);
     b.flags = c.take<uint32_t>(nbc);
-    b.lists = c.take<float>(nbc * kLinLists * lin_cap(s));
+    b.lists = reinterpret_cast<float *>(c.take<double>(nbc * kLinLists * lin_cap(s)));  // (sized for the float64 surface)
     return b;
 }
 
@@ -841,7 +862,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
     UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
-    UWIE_LAUNCH(k_lin_scan, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap);
+    UWIE_LAUNCH(k_lin_scan<float>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap);
     UWIE_LAUNCH_CHECK();
     static const char *env_cb = getenv("UWIE_COLLECT_BLOCKS");
     int blocks = env_cb ? atoi(env_cb) : (int)(((long long)n + 131071) / 131072);
@@ -855,10 +876,11 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
         const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
         UWIE_LAUNCH(k_lin_collect_src<4>, dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
     } else {
-        UWIE_LAUNCH(k_lin_collect, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, plan.lists, plan.cap);
+        UWIE_LAUNCH(k_lin_collect<float>, dim3(blocks, nbc), dim3(256), 0, st, (const float *)d_planar, n, lin, plan.lists, plan.cap);
     }
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_lin_finish, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, plan.lists, plan.cap, (float *)plan.os, plan.flags);
+    UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
+                plan.flags);
     UWIE_LAUNCH_CHECK();
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
@@ -870,6 +892,61 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
     return run_t<float>(plan, d_planar, 1, s, false, st, plan.flags);
+}
+
+// float64 planes (ES surface): the same selection without the prediction; the lists hold doubles
+int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan)
+{
+    UWIE_REQUIRE(nq >= 1 && nq <= kMaxPct, "percentiles: 1..4 percentiles per call");
+    const long long n = (long long)s.npx();
+    UWIE_REQUIRE(n >= 1 && n < (1ll << 31), "percentiles: plane size out of range");
+    Carver c(ws);
+    const int nbc = s.B * 3;
+    plan->state = c.take<SelState<uint64_t>>(nbc);
+    plan->ghist = c.take<uint32_t>((size_t)nbc * kMaxRanks * kBins);
+    plan->os = c.take<double>((size_t)nbc * kMaxRanks);
+    const LinBufs lb = carve_lin(c, s);
+    plan->lin = lb.lin;
+    plan->lists = lb.lists;
+    plan->flags = lb.flags;
+    plan->cap = lin_cap(s);
+    plan->nq = nq;
+    plan->is64 = true;
+    plan->predicted = false;
+    for (int j = 0; j < nq; ++j)
+        percentile_indices<double>(n, q_percent[j], &plan->ranks[2 * j], &plan->ranks[2 * j + 1], &plan->t[j]);
+    UWIE_HIP_CHECK(hipMemsetAsync(plan->ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    RankList ranks;
+    ranks.n = 2 * nq;
+    for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan->ranks[j];
+    UWIE_LAUNCH(k_lin_predict, dim3(nbc), dim3(256), 0, st, (LinState *)plan->lin, plan->ghist, ranks, (uint32_t)n, 0u, 0);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int select_lin_run64(const SelectPlan &plan, const double *d_planar, Shape s, hipStream_t st)
+{
+    const int n = (int)s.npx(), nbc = s.B * 3;
+    RankList ranks;
+    ranks.n = 2 * plan.nq;
+    for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
+    LinState *lin = (LinState *)plan.lin;
+    double *lists = reinterpret_cast<double *>(plan.lists);
+    UWIE_LAUNCH(k_lin_scan<double>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (double *)plan.os, plan.flags, plan.cap);
+    UWIE_LAUNCH_CHECK();
+    int blocks = (int)(((long long)n + 131071) / 131072);
+    if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
+    blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    UWIE_LAUNCH(k_lin_collect<double>, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, lists, plan.cap);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_lin_finish<double>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const double *)lists, plan.cap, (double *)plan.os,
+                plan.flags);
+    UWIE_LAUNCH_CHECK();
+    // generic path for the flagged planes (its kernels return at once for the others)
+    UWIE_LAUNCH(k_sel_init<uint64_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint64_t> *)plan.state, nbc, ranks);
+    UWIE_LAUNCH_CHECK();
+    UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    return run_t<double>(plan, d_planar, 1, s, false, st, plan.flags);
 }
 
 size_t select_ws_bytes(Shape s)
