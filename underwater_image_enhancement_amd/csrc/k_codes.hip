@@ -29,11 +29,18 @@ __global__ void __launch_bounds__(256) k_frame_hist(const uint8_t *__restrict__ 
     for (int i = tid; i < 4 * 768; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const uint8_t *img = in + (size_t)b * npx * 3;
-    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        atomicAdd(&h[w][q[0]], 1u);
-        atomicAdd(&h[w][256 + q[1]], 1u);
-        atomicAdd(&h[w][512 + q[2]], 1u);
+    const bool aligned = (npx & 3) == 0;
+    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {  // four pixels = three dwords per thread
+        const int n = min(4, npx - p);
+        const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {
+                atomicAdd(&h[w][v.r[i]], 1u);
+                atomicAdd(&h[w][256 + v.g[i]], 1u);
+                atomicAdd(&h[w][512 + v.b[i]], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < 768; i += 256) {
@@ -340,10 +347,41 @@ __global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ 
     }
     __syncthreads();
     const size_t base = (size_t)b * npx * 3;
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < (size_t)npx * 3; i += (size_t)gridDim.x * 256) {
-        const int idx = (int)(i % 3) * 256 + codes[base + i];
-        if (out_u8) out_u8[base + i] = s_fu[idx];
-        if (out_f32) out_f32[base + i] = s_ff[idx];
+    const bool aligned = (npx & 3) == 0;  // 4-pixel groups are then dword aligned (devutil.h load_px4)
+    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        const Px4 v = load_px4(codes + base + (size_t)p * 3, n, aligned);
+        uint32_t r[4], g[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[i] = v.r[i];
+            g[i] = 256 + v.g[i];
+            bl[i] = 512 + v.b[i];
+        }
+        if (out_f32) {
+            float *o = out_f32 + base + (size_t)p * 3;
+            if (aligned && n == 4) {
+                float4 *o4 = reinterpret_cast<float4 *>(o);
+                o4[0] = make_float4(s_ff[r[0]], s_ff[g[0]], s_ff[bl[0]], s_ff[r[1]]);
+                o4[1] = make_float4(s_ff[g[1]], s_ff[bl[1]], s_ff[r[2]], s_ff[g[2]]);
+                o4[2] = make_float4(s_ff[bl[2]], s_ff[r[3]], s_ff[g[3]], s_ff[bl[3]]);
+            } else {
+                for (int i = 0; i < n; ++i) {
+                    o[3 * i] = s_ff[r[i]];
+                    o[3 * i + 1] = s_ff[g[i]];
+                    o[3 * i + 2] = s_ff[bl[i]];
+                }
+            }
+        }
+        if (out_u8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[i] = s_fu[r[i]];
+                g[i] = s_fu[g[i]];
+                bl[i] = s_fu[bl[i]];
+            }
+            store_px4(out_u8 + base + (size_t)p * 3, r, g, bl, n, aligned);
+        }
     }
 }
 
@@ -441,9 +479,16 @@ size_t codes_ws_bytes(Shape s, int tx, int ty)
 }
 
 // The five strategies that live in the code domain.  `f64` selects the ES arithmetic (float64 after the first
+// a few thousand blocks in all, many pixels each: a block pays 3072 LDS clears and up to 768 global atomics
+static dim3 hist_grid(Shape s)
+{
+    const int need = cdiv((long long)s.npx(), 1024);
+    return dim3(std::max(1, std::min(need, std::max(16, 6144 / std::max(s.B, 1)))), s.B);
+}
+
 int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_t st)
 {
-    UWIE_LAUNCH(k_frame_hist, dim3(grid_for(s.npx(), 1024), s.B), dim3(256), 0, st, d_in, (int)s.npx(), d_hist);
+    UWIE_LAUNCH(k_frame_hist, hist_grid(s), dim3(256), 0, st, d_in, (int)s.npx(), d_hist);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -464,7 +509,7 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
 
     UWIE_HIP_CHECK(hipMemsetAsync(B.hist_in, 0, sizeof(uint32_t) * (size_t)s.B * 768, st));
     UWIE_HIP_CHECK(hipMemsetAsync(B.hist_mid, 0, sizeof(uint32_t) * (size_t)s.B * 768, st));
-    UWIE_LAUNCH(k_frame_hist, gpx, blk, 0, st, d_in, (int)n, B.hist_in);
+    UWIE_LAUNCH(k_frame_hist, hist_grid(s), blk, 0, st, d_in, (int)n, B.hist_in);
     UWIE_LAUNCH_CHECK();
 
     ChainProg pre{}, post{};
