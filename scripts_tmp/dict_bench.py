@@ -15,7 +15,9 @@ def run(p, n=3):
     return (time.time()-t)/n*1e3
 for k in (1,2,3,4,5,6):
     p = dev.params(_lib.SURFACE_SIX, k, cast_correct=1)
-    print('six', k, round(run(p),2), 'ms for', B, 'frames')
+    dev.profile(True); dev.enhance_u8(fr,p); rows=dev.profile_rows(); dev.profile(False)
+    top=sorted(rows.items(), key=lambda kv:-kv[1][0])[:7]
+    print('six', k, round(run(p),2), 'ms;', ', '.join(f'{n}={v[0]:.2f}' for n,v in top))
 for k in range(5):
     p = dev.params(_lib.SURFACE_DICT, k)
     dev.profile(True); dev.enhance_u8(fr,p); rows=dev.profile_rows(); dev.profile(False)

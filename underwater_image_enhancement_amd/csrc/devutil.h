@@ -52,6 +52,19 @@ __device__ __forceinline__ Px4 load_px4(const uint8_t *p, int n, bool aligned)
     }
     return o;
 }
+// four pixels at any byte address (three unaligned dword loads)
+__device__ __forceinline__ Px4 load_px4_any(const uint8_t *p)
+{
+    typedef uint32_t __attribute__((aligned(1))) u32_a1;
+    const u32_a1 *w = reinterpret_cast<const u32_a1 *>(p);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    Px4 o;
+    o.r[0] = w0 & 255; o.g[0] = (w0 >> 8) & 255; o.b[0] = (w0 >> 16) & 255;
+    o.r[1] = w0 >> 24; o.g[1] = w1 & 255; o.b[1] = (w1 >> 8) & 255;
+    o.r[2] = (w1 >> 16) & 255; o.g[2] = w1 >> 24; o.b[2] = w2 & 255;
+    o.r[3] = (w2 >> 8) & 255; o.g[3] = (w2 >> 16) & 255; o.b[3] = w2 >> 24;
+    return o;
+}
 __device__ __forceinline__ void store_px4(uint8_t *p, const uint32_t *r, const uint32_t *g, const uint32_t *b, int n,
                                           bool aligned)
 {

@@ -571,8 +571,8 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     }
     int rc = run_chain(pre, B.hist_in, d_kind, B.lut_a_code, nullptr);
     if (rc != UWIE_OK) return rc;
-    UWIE_LAUNCH(k_codes_lab_lut, dim3(tx * ty, s.B), blk, 0, st, ctx->d_lab, d_in, B.lut_a_code, g, B.lab, B.tile_lut);
-    UWIE_LAUNCH_CHECK();
+    rc = launch_codes_lab_lut(ctx, d_in, B.lut_a_code, s, p->clip_limit, tx, ty, B.lab, B.tile_lut, st);
+    if (rc != UWIE_OK) return rc;
     if (post_needs_hist) {
         UWIE_LAUNCH(k_clahe_apply_codes, gpx, blk, 0, st, ctx->d_lab, B.lab, B.tile_lut, g, (const uint8_t *)nullptr,
                     (const float *)nullptr, (uint8_t *)nullptr, (float *)nullptr, B.codes, B.hist_mid);

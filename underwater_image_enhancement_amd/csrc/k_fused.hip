@@ -232,12 +232,14 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *ws
     return incl;
 }
 
-// grid (tx*ty, B), block 256.  SRC: the restored image is recomputed from S (restore.h) instead of read from planar.
-template <bool SRC>
+// grid (tx*ty, B), block 256.  SRC 0: stored planes; 1: the restored image is recomputed from src (restore.h); 2: the
+// code-domain strategies (k_codes.hip): the u8 frame src.in goes through a per-(image, channel) code LUT (codes) and the
+// stretch is skipped.
+template <int SRC>
 __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__restrict__ T, const float *__restrict__ planar,
                                                          RestoreSrc src, const float *__restrict__ pct, int pct_stride,
-                                                         float eps, int two, ClaheGeom g, uint8_t *__restrict__ lab,
-                                                         uint8_t *__restrict__ lut)
+                                                         float eps, int two, const uint8_t *__restrict__ codes, ClaheGeom g,
+                                                         uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
 {
     __shared__ uint32_t h[4][256];
     __shared__ uint32_t wsum[4];
@@ -248,14 +250,18 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     for (int i = tid; i < 256; i += 256) s_gamma[i] = T->gamma[i];
     for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
     if (tid < 9) s_fwd[tid] = T->fwd[tid];
+    __shared__ uint16_t s_gcode[SRC == 2 ? 768 : 1];  // gamma table after the code LUT, per channel
     Stretch S;
-    S.load(pct, b, pct_stride, eps, two);
+    if (SRC != 2) S.load(pct, b, pct_stride, eps, two);
+    if (SRC == 2)
+        for (int i = tid; i < 768; i += 256) s_gcode[i] = T->gamma[codes[(size_t)b * 768 + i]];
     __syncthreads();
     const int npx = g.H * g.W;
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
-    __shared__ float dtab[SRC ? 768 : 1];
+    const uint8_t *img8 = src.in + (size_t)b * npx * 3;
+    __shared__ float dtab[SRC == 1 ? 768 : 1];
     RestoreImgT<true> R;
-    if (SRC) {
+    if (SRC == 1) {
         R.init(src, b, (size_t)npx, dtab);
         __syncthreads();
     }
@@ -265,9 +271,10 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     constexpr int Lscale = (116 * 255 + 50) / 100;
     constexpr int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
     auto to_lab = [&](float v0, float v1, float v2, uint32_t &L, uint32_t &a, uint32_t &bb) {
-        const int R = s_gamma[quant_u8(S.apply(v0, 0))];
-        const int G = s_gamma[quant_u8(S.apply(v1, 1))];
-        const int B = s_gamma[quant_u8(S.apply(v2, 2))];
+        // SRC 2: v0..v2 carry the frame's bytes
+        const int R = SRC == 2 ? s_gcode[(int)v0] : s_gamma[quant_u8(S.apply(v0, 0))];
+        const int G = SRC == 2 ? s_gcode[256 + (int)v1] : s_gamma[quant_u8(S.apply(v1, 1))];
+        const int B = SRC == 2 ? s_gcode[512 + (int)v2] : s_gamma[quant_u8(S.apply(v2, 2))];
         const int fX = s_cbrt[UWIE_DESCALE(R * s_fwd[0] + G * s_fwd[1] + B * s_fwd[2], 12)];
         const int fY = s_cbrt[UWIE_DESCALE(R * s_fwd[3] + G * s_fwd[4] + B * s_fwd[5], 12)];
         const int fZ = s_cbrt[UWIE_DESCALE(R * s_fwd[6] + G * s_fwd[7] + B * s_fwd[8], 12)];
@@ -283,7 +290,15 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
         const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr
         const int x0 = x_lo + 4 * xg, n = min(4, x_hi - x0), p = (y_lo + row) * g.W + x0;
         float v0[4], v1[4], v2[4];
-        if (SRC) {
+        if (SRC == 2) {
+            const Px4 q = n == 4 ? load_px4_any(img8 + (size_t)p * 3) : load_px4(img8 + (size_t)p * 3, n, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v0[i] = (float)q.r[i];
+                v1[i] = (float)q.g[i];
+                v2[i] = (float)q.b[i];
+            }
+        } else if (SRC == 1) {
             float r[3][4];
             R.four(p, n, r);
 #pragma unroll
@@ -342,7 +357,11 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
             const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
             uint32_t L, a, bb;
             float e0, e1, e2;
-            if (SRC) {
+            if (SRC == 2) {
+                e0 = (float)img8[(size_t)p * 3];
+                e1 = (float)img8[(size_t)p * 3 + 1];
+                e2 = (float)img8[(size_t)p * 3 + 2];
+            } else if (SRC == 1) {
                 R.pixel(p, e0, e1, e2);
             } else {
                 e0 = r0[p];
@@ -551,15 +570,53 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
     Stretch S;
     S.load(pct, b, pct_stride, eps, two);
     const float *r = planar + (size_t)b * 3 * npx;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const size_t o = ((size_t)b * npx + p) * 3;
+    const bool aligned = (npx & 3) == 0;  // plane rows of four floats are 16-byte aligned, output groups dword aligned
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {  // four pixels per thread
+        const int n = min(4, npx - p);
+        float v[3][4];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float y = S.apply_exact(r[(size_t)c * npx + p], c);
-            if (gamma_mode == 1) y = pow_f32(y, gexp);
-            else if (gamma_mode == 2) y = clip01(pow_f32(y, gexp));
-            if (out_u8) out_u8[o + c] = (uint8_t)quant_u8(y);
-            if (out_f32) out_f32[o + c] = y;
+            const float *src = r + (size_t)c * npx + p;
+            if (aligned && n == 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[c][i] = i < n ? src[i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y = S.apply_exact(v[c][i], c);
+                if (gamma_mode == 1) y = pow_f32(y, gexp);
+                else if (gamma_mode == 2) y = clip01(pow_f32(y, gexp));
+                v[c][i] = y;
+            }
+        }
+        const size_t o = ((size_t)b * npx + p) * 3;
+        if (out_f32) {
+            float *dst = out_f32 + o;
+            if (aligned && n == 4) {
+                float4 *d4 = reinterpret_cast<float4 *>(dst);
+                d4[0] = make_float4(v[0][0], v[1][0], v[2][0], v[0][1]);
+                d4[1] = make_float4(v[1][1], v[2][1], v[0][2], v[1][2]);
+                d4[2] = make_float4(v[2][2], v[0][3], v[1][3], v[2][3]);
+            } else {
+                for (int i = 0; i < n; ++i) {
+                    dst[3 * i] = v[0][i];
+                    dst[3 * i + 1] = v[1][i];
+                    dst[3 * i + 2] = v[2][i];
+                }
+            }
+        }
+        if (out_u8) {
+            uint32_t q0[4], q1[4], q2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                q0[i] = quant_u8(v[0][i]);
+                q1[i] = quant_u8(v[1][i]);
+                q2[i] = quant_u8(v[2][i]);
+            }
+            store_px4(out_u8 + o, q0, q1, q2, n, aligned);
         }
     }
 }
@@ -724,11 +781,11 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     uint8_t *lab = c.take<uint8_t>((size_t)s.B * s.npx() * 3);
     const ClaheGeom g = make_geom(s, clip, tx, ty);
     if (src)
-        UWIE_LAUNCH(k_stretch_lab_lut<true>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, *src, d_pct,
-                    pct_stride, eps, two, g, lab, lut);
+        UWIE_LAUNCH(k_stretch_lab_lut<1>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, *src, d_pct, pct_stride,
+                    eps, two, (const uint8_t *)nullptr, g, lab, lut);
     else
-        UWIE_LAUNCH(k_stretch_lab_lut<false>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, RestoreSrc{},
-                    d_pct, pct_stride, eps, two, g, lab, lut);
+        UWIE_LAUNCH(k_stretch_lab_lut<0>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, RestoreSrc{}, d_pct,
+                    pct_stride, eps, two, (const uint8_t *)nullptr, g, lab, lut);
     UWIE_LAUNCH_CHECK();
     // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
     const int cells = (tx + 1) * (ty + 1);
@@ -741,10 +798,23 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     return UWIE_OK;
 }
 
+// code-domain strategies (k_codes.hip): u8 frame -> per-(image, channel) code LUT -> RGB2LAB -> LAB bytes + tile LUTs
+int launch_codes_lab_lut(uwie_ctx *ctx, const uint8_t *d_in, const uint8_t *d_code_lut, Shape s, double clip, int tx, int ty,
+                         uint8_t *d_lab, uint8_t *d_tile_lut, hipStream_t st)
+{
+    const ClaheGeom g = make_geom(s, clip, tx, ty);
+    RestoreSrc src{};
+    src.in = d_in;
+    UWIE_LAUNCH(k_stretch_lab_lut<2>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, (const float *)nullptr, src,
+                (const float *)nullptr, 0, 0.0f, 0, d_code_lut, g, d_lab, d_tile_lut);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
 int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
                       int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st)
 {
-    UWIE_LAUNCH(k_stretch_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, d_planar, d_pct, pct_stride, eps, two,
+    UWIE_LAUNCH(k_stretch_out, dim3(grid_for(s.npx(), 4096), s.B), dim3(256), 0, st, d_planar, d_pct, pct_stride, eps, two,
                 (int)s.npx(), gamma_mode, gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
