@@ -285,6 +285,9 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
                       float *d_out_f32, void *ws, hipStream_t st, const RestoreSrc *src = nullptr);
 int launch_codes_lab_lut(uwie_ctx *ctx, const uint8_t *d_in, const uint8_t *d_code_lut, Shape s, double clip, int tx, int ty,
                          uint8_t *d_lab, uint8_t *d_tile_lut, hipStream_t st);
+int launch_clahe_apply_codes(uwie_ctx *ctx, const uint8_t *d_lab, const uint8_t *d_tile_lut, Shape s, double clip, int tx,
+                             int ty, const uint8_t *d_fin_code, const float *d_fin_val, uint8_t *d_out_u8, float *d_out_f32,
+                             uint8_t *d_codes_out, uint32_t *d_hist, hipStream_t st);
 int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride, float eps, int two, Shape s,
                       int gamma_mode, double gamma, uint8_t *d_out_u8, float *d_out_f32, hipStream_t st);
 // ES surface (float64): recover_image (ES:237-249) -> planar float64 + first select digit; color_enhancement

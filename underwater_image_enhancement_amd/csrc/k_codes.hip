@@ -170,168 +170,8 @@ __global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ frame kernels
-struct ClaheGeom {
-    int H, W, tx, ty, tw, th, clip;
-    float lutScale;
-};
-
-// u8 frame --(per image/channel code LUT)--> RGB2LAB -> LAB bytes + tile histogram -> tile LUT.  grid (tiles, B)
-__global__ void __launch_bounds__(256) k_codes_lab_lut(const LabTables *__restrict__ T, const uint8_t *__restrict__ in,
-                                                       const uint8_t *__restrict__ code_lut, ClaheGeom g,
-                                                       uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
-{
-    __shared__ uint32_t h[4][256];
-    __shared__ uint32_t wsum[4];
-    __shared__ uint16_t s_gamma[256], s_cbrt[3072];
-    __shared__ int s_fwd[9];
-    __shared__ uint8_t s_code[768];
-    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
-    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
-    s_gamma[tid] = T->gamma[tid];
-    for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
-    for (int i = tid; i < 768; i += 256) s_code[i] = code_lut[(size_t)b * 768 + i];
-    if (tid < 9) s_fwd[tid] = T->fwd[tid];
-    __syncthreads();
-    const int npx = g.H * g.W;
-    const uint8_t *img = in + (size_t)b * npx * 3;
-    uint8_t *labimg = lab + (size_t)b * npx * 3;
-    const int ty = tile / g.tx, txi = tile % g.tx;
-    const int area = g.tw * g.th;
-    constexpr int Lscale = (116 * 255 + 50) / 100;
-    constexpr int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
-    for (int i = tid; i < area; i += 256) {
-        const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
-        const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
-        const uint8_t *q = img + (size_t)p * 3;
-        const int R = s_gamma[s_code[q[0]]], G = s_gamma[s_code[256 + q[1]]], B = s_gamma[s_code[512 + q[2]]];
-        const int fX = s_cbrt[UWIE_DESCALE(R * s_fwd[0] + G * s_fwd[1] + B * s_fwd[2], 12)];
-        const int fY = s_cbrt[UWIE_DESCALE(R * s_fwd[3] + G * s_fwd[4] + B * s_fwd[5], 12)];
-        const int fZ = s_cbrt[UWIE_DESCALE(R * s_fwd[6] + G * s_fwd[7] + B * s_fwd[8], 12)];
-        const uint8_t L = sat_u8(UWIE_DESCALE(Lscale * fY + Lshift, 15));
-        atomicAdd(&h[w][L], 1u);
-        if (ey < g.H && ex < g.W) {
-            uint8_t *o = labimg + (size_t)p * 3;
-            o[0] = L;
-            o[1] = sat_u8(UWIE_DESCALE(500 * (fX - fY) + 128 * (1 << 15), 15));
-            o[2] = sat_u8(UWIE_DESCALE(200 * (fY - fZ) + 128 * (1 << 15), 15));
-        }
-    }
-    __syncthreads();
-    uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
-    if (g.clip > 0) {
-        const uint32_t over = c > (uint32_t)g.clip ? c - g.clip : 0;
-        if (over) c = g.clip;
-        const uint32_t tot = block_incl_scan_256(over, wsum);
-        __syncthreads();
-        if (tid == 255) wsum[0] = tot;
-        __syncthreads();
-        const uint32_t clipped = wsum[0];
-        __syncthreads();
-        const uint32_t batch = clipped / 256, residual = clipped - batch * 256;
-        c += batch;
-        if (residual) {
-            const uint32_t step = max(256u / residual, 1u);
-            if (tid % step == 0 && tid / step < residual) c += 1;
-        }
-    }
-    const uint32_t sum = block_incl_scan_256(c, wsum);
-    lut[((size_t)b * g.tx * g.ty + tile) * 256 + tid] = sat_u8(__float2int_rn((float)sum * g.lutScale));
-}
-
-__device__ __forceinline__ int ab_to_xz(int i)
-{
-    return i <= 3390 ? i * 108 / 841 - (1 << 14) * 16 / 116 * 108 / 841 : i * i / (1 << 14) * i / (1 << 14);
-}
-
-// CLAHE blend -> LAB2RGB -> RGB codes.  Either the codes go out through the final per-(image, channel) LUTs
-// (fin_code / fin_val given), or they are stored raw together with their per-channel histogram (codes_out / hist)
-// because the rest of the chain needs percentiles of them.  grid (n, B)
-__global__ void __launch_bounds__(256) k_clahe_apply_codes(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
-                                                           const uint8_t *__restrict__ lut, ClaheGeom g,
-                                                           const uint8_t *__restrict__ fin_code,
-                                                           const float *__restrict__ fin_val, uint8_t *__restrict__ out_u8,
-                                                           float *__restrict__ out_f32, uint8_t *__restrict__ codes_out,
-                                                           uint32_t *__restrict__ hist)
-{
-    __shared__ int s_ltoyf[512];
-    __shared__ uint8_t s_invgamma[4096];
-    __shared__ int s_inv[9];
-    __shared__ float s_ff[768];
-    __shared__ uint8_t s_fu[768];
-    __shared__ uint32_t h[4][768];
-    const int tid = threadIdx.x, b = blockIdx.y, w = tid >> 6;
-    for (int i = tid; i < 512; i += 256) s_ltoyf[i] = T->ltoyf[i];
-    for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
-    if (tid < 9) s_inv[tid] = T->inv[tid];
-    for (int i = tid; i < 768; i += 256) {
-        s_fu[i] = fin_code ? fin_code[(size_t)b * 768 + i] : (uint8_t)0;
-        s_ff[i] = fin_val ? fin_val[(size_t)b * 768 + i] : 0.f;
-    }
-    if (hist)
-        for (int i = tid; i < 4 * 768; i += 256) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const int npx = g.H * g.W;
-    const float inv_tw = 1.0f / (float)g.tw, inv_th = 1.0f / (float)g.th;
-    const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
-    constexpr int BASE = 1 << 14;
-    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
-        const int y = p / g.W, x = p % g.W;
-        const float tyf = (float)y * inv_th - 0.5f;
-        int ty1 = (int)floorf(tyf);
-        int ty2 = ty1 + 1;
-        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
-        ty1 = max(ty1, 0);
-        ty2 = min(ty2, g.ty - 1);
-        const float txf = (float)x * inv_tw - 0.5f;
-        int tx1 = (int)floorf(txf);
-        int tx2 = tx1 + 1;
-        const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
-        tx1 = max(tx1, 0);
-        tx2 = min(tx2, g.tx - 1);
-        const uint8_t *q = lab + ((size_t)b * npx + p) * 3;
-        const int v = q[0], aa = q[1], bb = q[2];
-        const float l11 = (float)Lt[(ty1 * g.tx + tx1) * 256 + v], l12 = (float)Lt[(ty1 * g.tx + tx2) * 256 + v];
-        const float l21 = (float)Lt[(ty2 * g.tx + tx1) * 256 + v], l22 = (float)Lt[(ty2 * g.tx + tx2) * 256 + v];
-        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
-        const int LL = sat_u8(__float2int_rn(res));
-        const int yy = s_ltoyf[LL * 2], ify = s_ltoyf[LL * 2 + 1];
-        const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
-        const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
-        const int xx = ab_to_xz(ify + adiv), zz = ab_to_xz(ify - bdiv);
-        const int ro = min(max(UWIE_DESCALE(s_inv[0] * xx + s_inv[1] * yy + s_inv[2] * zz, 14), 0), 4095);
-        const int go = min(max(UWIE_DESCALE(s_inv[3] * xx + s_inv[4] * yy + s_inv[5] * zz, 14), 0), 4095);
-        const int bo = min(max(UWIE_DESCALE(s_inv[6] * xx + s_inv[7] * yy + s_inv[8] * zz, 14), 0), 4095);
-        const int c0 = s_invgamma[ro], c1 = 256 + s_invgamma[go], c2 = 512 + s_invgamma[bo];
-        const size_t o = ((size_t)b * npx + p) * 3;
-        if (codes_out) {
-            codes_out[o] = (uint8_t)c0;
-            codes_out[o + 1] = (uint8_t)c1;
-            codes_out[o + 2] = (uint8_t)c2;
-        }
-        if (hist) {
-            atomicAdd(&h[w][c0], 1u);
-            atomicAdd(&h[w][c1], 1u);
-            atomicAdd(&h[w][c2], 1u);
-        }
-        if (out_u8) {
-            out_u8[o] = s_fu[c0];
-            out_u8[o + 1] = s_fu[c1];
-            out_u8[o + 2] = s_fu[c2];
-        }
-        if (out_f32) {
-            out_f32[o] = s_ff[c0];
-            out_f32[o + 1] = s_ff[c1];
-            out_f32[o + 2] = s_ff[c2];
-        }
-    }
-    if (hist) {
-        __syncthreads();
-        for (int i = tid; i < 768; i += 256) {
-            const uint32_t c = h[0][i] + h[1][i] + h[2][i] + h[3][i];
-            if (c) atomicAdd(&hist[(size_t)b * 768 + i], c);
-        }
-    }
-}
+// (the LAB / CLAHE stages are k_fused.hip's tile and cell kernels in their code-domain modes: launch_codes_lab_lut,
+// launch_clahe_apply_codes)
 
 // u8 HWC codes -> outputs through per-(image, channel) LUTs.  grid (n, B)
 __global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ codes, const uint8_t *__restrict__ fin_code,
@@ -385,26 +225,6 @@ __global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ 
     }
 }
 
-ClaheGeom make_geom(Shape s, double clip, int tx, int ty)
-{
-    ClaheGeom g;
-    g.H = s.H; g.W = s.W; g.tx = tx; g.ty = ty;
-    int We = s.W, He = s.H;
-    if (s.W % tx != 0 || s.H % ty != 0) {
-        We = s.W + (tx - s.W % tx);
-        He = s.H + (ty - s.H % ty);
-    }
-    g.tw = We / tx;
-    g.th = He / ty;
-    const int area = g.tw * g.th;
-    g.lutScale = (float)(256 - 1) / (float)area;
-    g.clip = 0;
-    if (clip > 0.0) {
-        g.clip = (int)(clip * area / 256);
-        if (g.clip < 1) g.clip = 1;
-    }
-    return g;
-}
 
 // np.percentile's index arithmetic: float32 for float32 data (S6 surface), float64 for float64 data (ES surface)
 void stretch_op(ChainOp *op, long long n, double lo_pct, double hi_pct, bool f64)
@@ -504,7 +324,6 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     const bool es = p->surface == UWIE_SURFACE_DICT;
     const int k = p->strategy;
     const dim3 gpx(grid_for(s.npx(), 1024), s.B), blk(256);
-    const ClaheGeom g = make_geom(s, p->clip_limit, tx, ty);
     const double wb = p->wb_percentile;
 
     UWIE_HIP_CHECK(hipMemsetAsync(B.hist_in, 0, sizeof(uint32_t) * (size_t)s.B * 768, st));
@@ -574,9 +393,9 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     rc = launch_codes_lab_lut(ctx, d_in, B.lut_a_code, s, p->clip_limit, tx, ty, B.lab, B.tile_lut, st);
     if (rc != UWIE_OK) return rc;
     if (post_needs_hist) {
-        UWIE_LAUNCH(k_clahe_apply_codes, gpx, blk, 0, st, ctx->d_lab, B.lab, B.tile_lut, g, (const uint8_t *)nullptr,
-                    (const float *)nullptr, (uint8_t *)nullptr, (float *)nullptr, B.codes, B.hist_mid);
-        UWIE_LAUNCH_CHECK();
+        rc = launch_clahe_apply_codes(ctx, B.lab, B.tile_lut, s, p->clip_limit, tx, ty, nullptr, nullptr, nullptr, nullptr, B.codes,
+                                      B.hist_mid, st);
+        if (rc != UWIE_OK) return rc;
         rc = run_chain(post, B.hist_mid, nullptr, B.fin_code, B.fin_val);
         if (rc != UWIE_OK) return rc;
         UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, B.codes, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32);
@@ -586,10 +405,8 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     // the post chain has no percentile: its LUT does not depend on the image, evaluate it on a flat histogram
     rc = run_chain(post, B.hist_in, nullptr, B.fin_code, B.fin_val);
     if (rc != UWIE_OK) return rc;
-    UWIE_LAUNCH(k_clahe_apply_codes, gpx, blk, 0, st, ctx->d_lab, B.lab, B.tile_lut, g, B.fin_code, B.fin_val, d_out_u8,
-                d_out_f32, (uint8_t *)nullptr, (uint32_t *)nullptr);
-    UWIE_LAUNCH_CHECK();
-    return UWIE_OK;
+    return launch_clahe_apply_codes(ctx, B.lab, B.tile_lut, s, p->clip_limit, tx, ty, B.fin_code, B.fin_val, d_out_u8, d_out_f32,
+                                    nullptr, nullptr, st);
 }
 
 }  // namespace uwie

@@ -416,16 +416,23 @@ __device__ __forceinline__ int ab_to_xz(int i)
 // covers a boundary pixel that float rounding puts into the next cell) into LDS once; the four per-pixel LUT gathers
 // then hit LDS instead of global memory, where they made the kernel address-unit bound.
 // grid ((tx+1)*(ty+1)*nchunk, B), block 256
+// CODES (code-domain strategies, k_codes.hip): the RGB codes go out through per-(image, channel) final LUTs (fin_code /
+// fin_val) or are stored raw with their per-channel histogram (codes_out / hist: the rest of the chain needs percentiles).
+template <bool CODES>
 __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__restrict__ T, const uint8_t *__restrict__ lab,
                                                          const uint8_t *__restrict__ lut, ClaheGeom g, int nchunk,
-                                                         int gamma_mode, float gexp, uint8_t *__restrict__ out_u8,
-                                                         float *__restrict__ out_f32)
+                                                         int gamma_mode, float gexp, const uint8_t *__restrict__ fin_code,
+                                                         const float *__restrict__ fin_val, uint8_t *__restrict__ out_u8,
+                                                         float *__restrict__ out_f32, uint8_t *__restrict__ codes_out,
+                                                         uint32_t *__restrict__ hist)
 {
+    constexpr int NF = CODES ? 768 : 256;
     __shared__ int s_ltoyf[512];
     __shared__ uint8_t s_invgamma[4096];
     __shared__ int s_inv[9];
-    __shared__ float s_ff[256];
-    __shared__ uint8_t s_fu[256];
+    __shared__ float s_ff[NF];
+    __shared__ uint8_t s_fu[NF];
+    __shared__ uint32_t s_h[CODES ? 4 * 768 : 1];
     __shared__ __attribute__((aligned(4))) uint8_t s_lut[16][256];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cell = blockIdx.x / nchunk, chunk = blockIdx.x - cell * nchunk;
@@ -440,7 +447,14 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     for (int i = tid; i < 512; i += 256) s_ltoyf[i] = T->ltoyf[i];
     for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
     if (tid < 9) s_inv[tid] = T->inv[tid];
-    {
+    if (CODES) {
+        for (int i = tid; i < 768; i += 256) {
+            s_fu[i] = fin_code ? fin_code[(size_t)b * 768 + i] : (uint8_t)0;
+            s_ff[i] = fin_val ? fin_val[(size_t)b * 768 + i] : 0.f;
+        }
+        if (hist)
+            for (int i = tid; i < 4 * 768; i += 256) s_h[i] = 0;
+    } else {
         const float y = final_value(tid, gamma_mode, gexp);
         s_ff[tid] = y;
         s_fu[tid] = (uint8_t)quant_u8(y);
@@ -522,6 +536,31 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
             o2[i] = s_invgamma[bo];
         }
         const size_t o = pix * 3;
+        if (CODES) {
+            if (codes_out) {
+                if (n == 4) {
+                    u32_unaligned *w = reinterpret_cast<u32_unaligned *>(codes_out + o);
+                    w[0] = o0[0] | (o1[0] << 8) | (o2[0] << 16) | (o0[1] << 24);
+                    w[1] = o1[1] | (o2[1] << 8) | (o0[2] << 16) | (o1[2] << 24);
+                    w[2] = o2[2] | (o0[3] << 8) | (o1[3] << 16) | (o2[3] << 24);
+                } else {
+                    store_px4(codes_out + o, o0, o1, o2, n, false);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o1[i] += 256;
+                o2[i] += 512;
+            }
+            if (hist) {
+                uint32_t *hw = s_h + (tid >> 6) * 768;
+                for (int i = 0; i < n; ++i) {
+                    atomicAdd(&hw[o0[i]], 1u);
+                    atomicAdd(&hw[o1[i]], 1u);
+                    atomicAdd(&hw[o2[i]], 1u);
+                }
+            }
+        }
         if (out_f32)
             for (int i = 0; i < n; ++i) {
                 out_f32[o + 3 * i] = s_ff[o0[i]];
@@ -557,6 +596,13 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         for (int gi = tid; gi < total; gi += 256) {
             const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr (gi < 2^32 / gpr)
             group(row, xg, cols_of(cx0 + 4 * xg));
+        }
+    }
+    if (CODES && hist) {
+        __syncthreads();
+        for (int i = tid; i < 768; i += 256) {
+            const uint32_t c = s_h[i] + s_h[768 + i] + s_h[2 * 768 + i] + s_h[3 * 768 + i];
+            if (c) atomicAdd(&hist[(size_t)b * 768 + i], c);
         }
     }
 }
@@ -792,8 +838,24 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     static const char *env_nc = getenv("UWIE_CLAHE_CHUNKS");
     int nchunk = env_nc ? atoi(env_nc) : cdiv(25920, cells * s.B);  // ~12 rounds of the 2048 resident blocks
     nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
-    UWIE_LAUNCH(k_clahe_apply_out, dim3(cells * nchunk, s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g, nchunk, gamma_mode,
-                gamma_exponent(gamma_mode, gamma), d_out_u8, d_out_f32);
+    UWIE_LAUNCH(k_clahe_apply_out<false>, dim3(cells * nchunk, s.B), dim3(256), 0, st, ctx->d_lab, lab, lut, g, nchunk,
+                gamma_mode, gamma_exponent(gamma_mode, gamma), (const uint8_t *)nullptr, (const float *)nullptr, d_out_u8,
+                d_out_f32, (uint8_t *)nullptr, (uint32_t *)nullptr);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+// code-domain strategies (k_codes.hip): CLAHE blend -> LAB2RGB -> RGB codes -> final per-channel LUTs, or raw codes + histogram
+int launch_clahe_apply_codes(uwie_ctx *ctx, const uint8_t *d_lab, const uint8_t *d_tile_lut, Shape s, double clip, int tx,
+                             int ty, const uint8_t *d_fin_code, const float *d_fin_val, uint8_t *d_out_u8, float *d_out_f32,
+                             uint8_t *d_codes_out, uint32_t *d_hist, hipStream_t st)
+{
+    const ClaheGeom g = make_geom(s, clip, tx, ty);
+    const int cells = (tx + 1) * (ty + 1);
+    int nchunk = cdiv(25920, cells * s.B);
+    nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
+    UWIE_LAUNCH(k_clahe_apply_out<true>, dim3(cells * nchunk, s.B), dim3(256), 0, st, ctx->d_lab, d_lab, d_tile_lut, g, nchunk,
+                0, 1.0f, d_fin_code, d_fin_val, d_out_u8, d_out_f32, d_codes_out, d_hist);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
