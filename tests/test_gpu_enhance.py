@@ -127,6 +127,31 @@ def test_dict_surface_matches_oracle(uw, orc, name):
                 assert np.abs(got.astype(np.float64) - want).max() < 1e-6
 
 
+def test_dict_surface_select_and_store_modes(uw, orc, monkeypatch):
+    """The dict surface's dehazing strategies take their float64 percentiles from the linear-digit selection on an image
+    that is recomputed per sweep (default); the stored-plane mode, the forced fallback to the generic key sweeps (tiny
+    candidate lists: flagged planes are written out first) and the generic sweeps alone must give the same floats."""
+    rng = np.random.default_rng(515)
+    noisy = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
+    flatish = np.empty((330, 310, 3), np.uint8)
+    flatish[:] = (90, 140, 180)
+    flatish[::7, ::5] = rng.integers(0, 256, flatish[::7, ::5].shape, dtype=np.uint8)
+    odd = rng.integers(0, 256, (131, 203, 3), dtype=np.uint8)
+    ES = orc.DictStrategyOracle
+    for name in ("strong_dehazing", "medium_dehazing", "light_enhancement"):
+        for tag, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd)):
+            x = orc.normalise_u8(u8)
+            want = ES.run(x, name, {}).astype(np.float32)
+            for env in ({}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_LIN_CAP": "16"}, {"UWIE_LIN_CAP": "16", "UWIE_RESTORE_STORE": "1"},
+                        {"UWIE_SELECT_GENERIC": "1"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                got = uw.EnhancementStrategies.apply_strategy(x, name, {})
+                for k in env:
+                    monkeypatch.delenv(k)
+                assert np.array_equal(got, want), (name, tag, env, int((got != want).sum()))
+
+
 def test_dict_surface_error_behaviour(uw, orc):
     rng = np.random.default_rng(5)
     x = orc.normalise_u8(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8))

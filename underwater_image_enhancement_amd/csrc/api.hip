@@ -156,7 +156,7 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
     // the restored image is clipped to [0, 1]: linear first digit, one collecting sweep (k_select.hip, select_lin_*);
     // UWIE_SELECT_GENERIC=1 keeps the three-digit key sweeps
-    static const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    const char *env_generic = getenv("UWIE_SELECT_GENERIC");  // read per call
     const RestoreSrc src{d_in, kind, P.A, P.t};
     bool recompute = false;
     if (env_generic && atoi(env_generic) == 1) {
@@ -212,17 +212,24 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
     // the recovered image is clipped to [0, 1]: linear first digit, one collecting sweep (select_lin_*64);
     // UWIE_SELECT_GENERIC=1 keeps the six-digit key sweeps
     const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    const RestoreSrc src{d_in, nullptr, P.A, P.t};
+    bool recompute = false;
     if (env_generic && atoi(env_generic) == 1) {
         UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
         UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st));
         UWIE_TRY(select_run64(plan, P.F64, 1, s, true, st));
     } else {
+        // the float64 image (24 B/px) is not stored either: histogram sweep, collecting sweep and stretch recompute it
+        // from the frame and t (11 B/px each); P.F64 only serves images that fall back to the generic sweeps.
+        // UWIE_RESTORE_STORE=1 keeps the stored planes.
+        const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call
+        recompute = !(env_store && atoi(env_store) == 1);
         UWIE_TRY(select_lin_begin64(s, q, 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st, true));
-        UWIE_TRY(select_lin_run64(plan, P.F64, s, st));
+        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, recompute ? nullptr : P.F64, plan.ghist, st, true));
+        UWIE_TRY(select_lin_run64(plan, P.F64, s, st, recompute ? &src : nullptr));
     }
     UWIE_TRY(select_lerp64(plan, s, P.pct64, st));
-    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st);
+    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st, recompute ? &src : nullptr);
 }
 
 int check_params(const uwie_params *p)

@@ -669,33 +669,48 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
 
 // ---- ES surface, float64
 // recovered = clip((img - A) / t + A, 0, 1): float32 difference, float64 quotient/sum/result (ES:247-248)
-// LIN: the histogram is over lin_digit() (select_lin_*64), else over the top 11 key bits
+// LIN: the histogram is over lin_digit() (select_lin_*64), else over the top 11 key bits.  planar == nullptr: histogram
+// only (the consumers recompute the image, restore.h four64); ghist == nullptr: image only; only != nullptr: images none
+// of whose planes is flagged are skipped.  Four pixels per thread.
 template <bool LIN>
-__global__ void __launch_bounds__(256) k_recover64_planar_hist(const uint8_t *__restrict__ in, const float *__restrict__ A,
-                                                               const double *__restrict__ t, int npx,
-                                                               double *__restrict__ planar, uint32_t *__restrict__ ghist)
+__global__ void __launch_bounds__(256) k_recover64_planar_hist(RestoreSrc S, int npx, double *__restrict__ planar,
+                                                               uint32_t *__restrict__ ghist,
+                                                               const uint32_t *__restrict__ only)
 {
     constexpr int NB = LIN ? 2052 : 2048;
     __shared__ uint32_t h[3][NB];
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const float a0 = A[b * 3 + 0], a1 = A[b * 3 + 1], a2 = A[b * 3 + 2];
-    const uint8_t *img = in + (size_t)b * npx * 3;
-    double *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
-    for (int p = blockIdx.x * 256 + tid; p < npx; p += gridDim.x * 256) {
-        const uint8_t *q = img + (size_t)p * 3;
-        const double tv = t[(size_t)b * npx + p];
-        const double r0 = fmin(fmax((double)(px_norm(q[0]) - a0) / tv + (double)a0, 0.0), 1.0);
-        const double r1 = fmin(fmax((double)(px_norm(q[1]) - a1) / tv + (double)a1, 0.0), 1.0);
-        const double r2 = fmin(fmax((double)(px_norm(q[2]) - a2) / tv + (double)a2, 0.0), 1.0);
-        o0[p] = r0;
-        o1[p] = r1;
-        o2[p] = r2;
-        atomicAdd(&h[0][LIN ? lin_digit(r0) : (uint32_t)(f64_key(r0) >> 53)], 1u);
-        atomicAdd(&h[1][LIN ? lin_digit(r1) : (uint32_t)(f64_key(r1) >> 53)], 1u);
-        atomicAdd(&h[2][LIN ? lin_digit(r2) : (uint32_t)(f64_key(r2) >> 53)], 1u);
+    if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
+    if (ghist) {
+        for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
+        __syncthreads();
     }
+    RestoreImg R;
+    R.init(S, b, (size_t)npx);
+    double *o[3] = {planar + (size_t)b * 3 * npx, planar + (size_t)b * 3 * npx + npx, planar + (size_t)b * 3 * npx + 2 * (size_t)npx};
+    const bool aligned = (npx & 1) == 0;  // plane rows of two doubles are 16-byte aligned
+    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        double r[3][4];
+        R.four64(p, n, r);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (planar) {
+                if (aligned && n == 4) {
+                    *reinterpret_cast<double2 *>(o[c] + p) = make_double2(r[c][0], r[c][1]);
+                    *reinterpret_cast<double2 *>(o[c] + p + 2) = make_double2(r[c][2], r[c][3]);
+                } else {
+                    for (int i = 0; i < n; ++i) o[c][p + i] = r[c][i];
+                }
+            }
+            if (ghist) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < n) atomicAdd(&h[c][LIN ? lin_digit(r[c][i]) : (uint32_t)(f64_key(r[c][i]) >> 53)], 1u);
+            }
+        }
+    }
+    if (!ghist) return;
     __syncthreads();
     for (int i = tid; i < 3 * NB; i += 256) {
         const uint32_t c = (&h[0][0])[i];
@@ -703,28 +718,75 @@ __global__ void __launch_bounds__(256) k_recover64_planar_hist(const uint8_t *__
     }
 }
 
-// pct: [B][3][2] float64 = lo, hi.  grid (n, B)
-__global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict__ planar, const double *__restrict__ pct,
-                                                       int npx, int apply_gamma, double gexp,
+// pct: [B][3][2] float64 = lo, hi.  grid (n, B), four pixels per thread.  SRC: the recovered image is recomputed from S
+// instead of read from planar.  The three stretch quotients of a channel share the denominator: the float64 division's
+// own sequence with the reciprocal kept (as restore.h does for the divisor t), true division outside its safe range.
+struct StretchDiv64 {
+    double den, y;
+    bool fast;
+    __device__ __forceinline__ void set(double d)
+    {
+        den = d;
+        fast = d >= 0x1p-100 && d <= 0x1p100;
+        double r = __builtin_amdgcn_rcp(d);
+        r = fma(r, fma(-d, r, 1.0), r);
+        y = fma(r, fma(-d, r, 1.0), r);
+    }
+    __device__ __forceinline__ double quot(double n) const
+    {
+        const double m = fabs(n);
+        if (!(fast && (m == 0.0 || (m >= 0x1p-500 && m <= 0x1p500)))) return n / den;
+        const double q0 = n * y;
+        return fma(fma(-den, q0, n), y, q0);
+    }
+};
+template <bool SRC>
+__global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict__ planar, RestoreSrc S,
+                                                       const double *__restrict__ pct, int npx, int apply_gamma, double gexp,
                                                        uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
 {
     const int b = blockIdx.y;
-    double lo[3], den[3];
+    double lo[3];
+    StretchDiv64 den[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         lo[c] = pct[(b * 3 + c) * 2];
-        den[c] = (pct[(b * 3 + c) * 2 + 1] - lo[c]) + 1e-10;
+        den[c].set((pct[(b * 3 + c) * 2 + 1] - lo[c]) + 1e-10);
     }
+    RestoreImg R;
+    if (SRC) R.init(S, b, (size_t)npx);
     const double *r = planar + (size_t)b * 3 * npx;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
-        const size_t o = ((size_t)b * npx + p) * 3;
+    const bool aligned = (npx & 3) == 0;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < npx; p += gridDim.x * 1024) {
+        const int n = min(4, npx - p);
+        double v[3][4];
+        if (SRC) {
+            R.four64(p, n, v);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double y = fmin(fmax((r[(size_t)c * npx + p] - lo[c]) / den[c], 0.0), 1.0);
-            if (apply_gamma) y = fmin(fmax(pow(y, gexp), 0.0), 1.0);
-            if (out_u8) out_u8[o + c] = (uint8_t)((int)(y * 255.0) & 0xff);
-            if (out_f32) out_f32[o + c] = (float)y;
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[c][i] = i < n ? r[(size_t)c * npx + p + i] : 0.0;
         }
+        uint32_t q[3][4];
+        float f[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double y = fmin(fmax(den[c].quot(v[c][i] - lo[c]), 0.0), 1.0);
+                if (apply_gamma) y = fmin(fmax(pow(y, gexp), 0.0), 1.0);
+                q[c][i] = (uint32_t)((int)(y * 255.0) & 0xff);
+                f[c][i] = (float)y;
+            }
+        const size_t o = ((size_t)b * npx + p) * 3;
+        if (out_u8) store_px4(out_u8 + o, q[0], q[1], q[2], n, aligned);
+        if (out_f32)
+            for (int i = 0; i < n; ++i) {
+                out_f32[o + 3 * i] = f[0][i];
+                out_f32[o + 3 * i + 1] = f[1][i];
+                out_f32[o + 3 * i + 2] = f[2][i];
+            }
     }
 }
 
@@ -785,27 +847,33 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 }
 
 int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
-                                 uint32_t *d_ghist, hipStream_t st, bool linear)
+                                 uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only)
 {
-    int nblk = 2048 / s.B;
-    nblk = nblk < 16 ? 16 : nblk > 256 ? 256 : nblk;
-    const int need = cdiv((long long)s.npx(), 256);
+    int nblk = cdiv(12288, s.B);
+    nblk = nblk < 16 ? 16 : nblk > 1024 ? 1024 : nblk;
+    const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
+    const RestoreSrc S{d_in, nullptr, d_A, d_t};
     const auto k_recover64_hist_lin = k_recover64_planar_hist<true>;  // (names as the profiler reports them)
     const auto k_recover64_hist_key = k_recover64_planar_hist<false>;
     if (linear)
-        UWIE_LAUNCH(k_recover64_hist_lin, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar, d_ghist);
+        UWIE_LAUNCH(k_recover64_hist_lin, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only);
     else
-        UWIE_LAUNCH(k_recover64_hist_key, dim3(nblk, s.B), dim3(256), 0, st, d_in, d_A, d_t, (int)s.npx(), d_planar, d_ghist);
+        UWIE_LAUNCH(k_recover64_hist_key, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
 
 int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
-                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st)
+                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src)
 {
-    UWIE_LAUNCH(k_stretch64_out, dim3(grid_for(s.npx(), 2048), s.B), dim3(256), 0, st, d_planar, d_pct, (int)s.npx(),
-                apply_gamma, 1.0 / gamma, d_out_u8, d_out_f32);
+    const dim3 grid(grid_for(s.npx(), 4096), s.B);
+    if (src)
+        UWIE_LAUNCH(k_stretch64_out<true>, grid, dim3(256), 0, st, d_planar, *src, d_pct, (int)s.npx(), apply_gamma, 1.0 / gamma,
+                    d_out_u8, d_out_f32);
+    else
+        UWIE_LAUNCH(k_stretch64_out<false>, grid, dim3(256), 0, st, d_planar, RestoreSrc{}, d_pct, (int)s.npx(), apply_gamma,
+                    1.0 / gamma, d_out_u8, d_out_f32);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

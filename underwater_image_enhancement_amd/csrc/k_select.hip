@@ -655,11 +655,12 @@ __global__ void __launch_bounds__(256) k_lin_collect(const V *__restrict__ vals,
 // The same sweep when the planes are not stored: grid (blocks, B), the block recomputes its pixels' three restored
 // values from the frame and the transmission (restore.h, 11 instead of 12 bytes per pixel and no stored copy) and
 // files each under its own channel's groups.  NG: most groups per channel (ranks of the call).
-template <int NG>
+template <typename V, int NG>
 __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, LinState *__restrict__ st,
-                                                         float *__restrict__ lists, uint32_t cap)
+                                                         V *__restrict__ lists, uint32_t cap)
 {
-    __shared__ float stg[3 * NG][kLinStage];
+    constexpr int kStage = sizeof(V) == 8 ? 256 : 512;  // 24 KB of LDS either way (V = double: the ES surface's float64 image)
+    __shared__ V stg[3 * NG][kStage];
     __shared__ uint32_t scount[3 * NG], sbase[3 * NG];
     const int b = blockIdx.y, tid = threadIdx.x;
     LinState *s = st + 3 * b;
@@ -678,14 +679,14 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     R.init(S, b, (size_t)n);
     const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
     const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
-    auto take = [&](int c, float x, bool live) {
-        const uint32_t d = (live && x > 0.0f) ? (uint32_t)(x * 2048.0f) : 0xfffffffeu;  // see k_lin_collect
+    auto take = [&](int c, V x, bool live) {
+        const uint32_t d = (live && x > (V)0) ? (uint32_t)(x * (V)2048) : 0xfffffffeu;  // see k_lin_collect
         uint32_t idx = kLinDone;
 #pragma unroll
         for (int g = 0; g < NG; ++g) idx = d == gd[c][g] ? (uint32_t)g : idx;
         if (idx != kLinDone) {
             const uint32_t pos = atomicAdd(&scount[c * NG + idx], 1u);
-            if (pos < (uint32_t)kLinStage) {
+            if (pos < (uint32_t)kStage) {
                 stg[c * NG + idx][pos] = x;
             } else {  // a burst: straight to the list
                 const uint32_t at = atomicAdd(&s[c].gcount[idx], 1u);
@@ -696,16 +697,16 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     auto flush = [&](bool force) {  // all threads of the block call
         __syncthreads();
         bool need = force;
-        for (int j = 0; j < 3 * NG; ++j) need = need || scount[j] > (uint32_t)(kLinStage * 3 / 4);
+        for (int j = 0; j < 3 * NG; ++j) need = need || scount[j] > (uint32_t)(kStage * 3 / 4);
         if (!need) return;  // block-uniform
         if (tid < 3 * NG) {
-            const uint32_t c = min(scount[tid], (uint32_t)kLinStage);
+            const uint32_t c = min(scount[tid], (uint32_t)kStage);
             if (c) sbase[tid] = atomicAdd(&s[tid / NG].gcount[tid % NG], c);
         }
         __syncthreads();
         for (int j = 0; j < 3 * NG; ++j) {
-            const uint32_t c = min(scount[j], (uint32_t)kLinStage), base = sbase[j];
-            float *L = lists + ((size_t)(3 * b + j / NG) * kLinLists + (j % NG)) * cap;
+            const uint32_t c = min(scount[j], (uint32_t)kStage), base = sbase[j];
+            V *L = lists + ((size_t)(3 * b + j / NG) * kLinLists + (j % NG)) * cap;
             for (uint32_t i = tid; i < c; i += 256)
                 if (base + i < cap) L[base + i] = stg[j][i];
         }
@@ -719,8 +720,9 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
         for (int u = 0; u < U; ++u) {
             const int p = base + u * 1024 + tid * 4, m = min(4, hi - p);
             if (m > 0) {
-                float r[3][4];
-                R.four(p, m, r);
+                V r[3][4];
+                if constexpr (sizeof(V) == 8) R.four64(p, m, r);
+                else R.four(p, m, r);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     take(0, r[0][i], i < m);
@@ -874,7 +876,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     if (plan.predicted && !env_cb) blocks = std::max(1, std::min(2 * blocks, cdiv(24576, nbc)));
     if (src) {
         const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
-        UWIE_LAUNCH(k_lin_collect_src<4>, dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
+        UWIE_LAUNCH((k_lin_collect_src<float, 4>), dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
     } else {
         UWIE_LAUNCH(k_lin_collect<float>, dim3(blocks, nbc), dim3(256), 0, st, (const float *)d_planar, n, lin, plan.lists, plan.cap);
     }
@@ -924,12 +926,13 @@ int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipSt
     return UWIE_OK;
 }
 
-int select_lin_run64(const SelectPlan &plan, const double *d_planar, Shape s, hipStream_t st)
+int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStream_t st, const RestoreSrc *src)
 {
     const int n = (int)s.npx(), nbc = s.B * 3;
     RankList ranks;
     ranks.n = 2 * plan.nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
+    UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run64: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
     double *lists = reinterpret_cast<double *>(plan.lists);
     UWIE_LAUNCH(k_lin_scan<double>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (double *)plan.os, plan.flags, plan.cap);
@@ -937,12 +940,23 @@ int select_lin_run64(const SelectPlan &plan, const double *d_planar, Shape s, hi
     int blocks = (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
-    UWIE_LAUNCH(k_lin_collect<double>, dim3(blocks, nbc), dim3(256), 0, st, d_planar, n, lin, lists, plan.cap);
+    if (src) {
+        const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
+        const auto k_lin_collect_src64 = k_lin_collect_src<double, 4>;
+        UWIE_LAUNCH(k_lin_collect_src64, dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, lists, plan.cap);
+    } else {
+        UWIE_LAUNCH(k_lin_collect<double>, dim3(blocks, nbc), dim3(256), 0, st, (const double *)d_planar, n, lin, lists, plan.cap);
+    }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<double>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const double *)lists, plan.cap, (double *)plan.os,
                 plan.flags);
     UWIE_LAUNCH_CHECK();
-    // generic path for the flagged planes (its kernels return at once for the others)
+    // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
+    // flagged images are written out first
+    if (src) {
+        const int rc = launch_recover64_planar_hist(src->in, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags);
+        if (rc != UWIE_OK) return rc;
+    }
     UWIE_LAUNCH(k_sel_init<uint64_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint64_t> *)plan.state, nbc, ranks);
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));

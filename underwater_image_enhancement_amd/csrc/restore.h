@@ -121,6 +121,46 @@ struct RestoreImgT {  // per image, in registers
             r2 = one(q[2], 2, tv);
         }
     }
+    // ---- ES surface (enhancement_strategies.py:237-249): the same expression kept in float64, clipped there
+    __device__ __forceinline__ double one64(uint32_t u, int c, double tv) const
+    {
+        return fmin(fmax((double)diff(u, c) / tv + (double)a[c], 0.0), 1.0);
+    }
+    __device__ __forceinline__ double one64_fast(uint32_t u, int c, double tv, double y) const
+    {
+        const double n = (double)diff(u, c), q0 = n * y;
+        return fmin(fmax(fma(fma(-tv, q0, n), y, q0) + (double)a[c], 0.0), 1.0);
+    }
+    __device__ __forceinline__ void four64(int p, int n, double (&r)[3][4]) const
+    {
+        Px4 v;
+        double tv[4];
+        if (n == 4) {
+            v = load_px4_any(img + (size_t)p * 3);
+            const double2_a8 ta = *reinterpret_cast<const double2_a8 *>(t + p), tb = *reinterpret_cast<const double2_a8 *>(t + p + 2);
+            tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
+        } else {
+            v = load_px4(img + (size_t)p * 3, n, false);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tv[i] = i < n ? t[p + i] : 1.0;
+        }
+        if (recip_ok(tv[0]) && recip_ok(tv[1]) && recip_ok(tv[2]) && recip_ok(tv[3])) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double y = recip(tv[i]);
+                r[0][i] = one64_fast(v.r[i], 0, tv[i], y);
+                r[1][i] = one64_fast(v.g[i], 1, tv[i], y);
+                r[2][i] = one64_fast(v.b[i], 2, tv[i], y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[0][i] = one64(v.r[i], 0, tv[i]);
+                r[1][i] = one64(v.g[i], 1, tv[i]);
+                r[2][i] = one64(v.b[i], 2, tv[i]);
+            }
+        }
+    }
 };
 
 using RestoreImg = RestoreImgT<false>;
