@@ -317,6 +317,9 @@ def test_select_paths_agree(uw, orc, monkeypatch):
                 monkeypatch.setenv("UWIE_LIN_CAP", "16")
                 check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, store={store}")
                 monkeypatch.delenv("UWIE_LIN_CAP")
+                monkeypatch.setenv("UWIE_SELECT_GENERIC", "1")
+                check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
+                monkeypatch.delenv("UWIE_SELECT_GENERIC")
                 if k != 3:  # the producer files predicted windows for strategies 1-2: off, still covering, missing
                     for knob, val in (("UWIE_LIN_NO_PREDICT", "1"), ("UWIE_LIN_PREDICT_SHIFT", "2"), ("UWIE_LIN_PREDICT_SHIFT", "400")):
                         monkeypatch.setenv(knob, val)
