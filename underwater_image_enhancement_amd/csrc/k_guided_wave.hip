@@ -43,10 +43,14 @@ struct WaveCfg {
     static constexpr int NV = kWaveSlots - 2 * (K - 1);  // output columns per strip
     static constexpr int RC = 2 * a + 1;  // ring rows: output row y2 = r1 - a needs a/b rows y2-a .. y2+Lb and, leaving, y2-1-a
     static constexpr int NL = (kWaveSlots - K) / 2 + 1;  // lanes that own a valid a/b slot; the rest share one dummy entry
-    static constexpr int NLp = NL + 1;
     static constexpr int SW = (64 + M + 2) & ~1;          // staging line: 64 lanes + the look-ahead of the last lane
-    static constexpr int ring_bytes = RC * 2 * NLp * 16;
     static constexpr int region_doubles = 6 * SW;         // up to 3 planes x {P, slot-0 value}
+    // The lanes without a valid a/b slot share one dummy ring entry, unless leaving it out (and masking those lanes'
+    // ring accesses) lets one more wavefront fit on the CU: k = 20, 41.3 KB -> 40.6 KB, 3 -> 4 wavefronts.
+    static constexpr int lds_with(int nlp) { return RC * 2 * nlp * 16 + NREG_ * region_doubles * 8; }
+    static constexpr bool kDummy = (160 * 1024) / lds_with(NL) == (160 * 1024) / lds_with(NL + 1);
+    static constexpr int NLp = kDummy ? NL + 1 : NL;
+    static constexpr int ring_bytes = RC * 2 * NLp * 16;
     // two staging regions (alternating) unless that costs a resident wavefront per CU
     // staging regions: 1 measured faster than 2 alternating ones (6.6 vs 7.4 ms at 4K x 64, k = 15): LDS bytes per
     // wavefront decide how many strips a CU holds (five up to 31.5 KB each, four beyond: measured), and that matters
@@ -205,7 +209,8 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
     extern __shared__ double2 ring[];  // [RC][2][NLp]: {a, b} of slot 2l (half 0) and of slot 2l+1 (half 1)
     double *stage = reinterpret_cast<double *>(ring) + C::ring_bytes / 8;
     const int lane = threadIdx.x;
-    const int rl = min(lane, C::NL);
+    const int rl = C::kDummy ? min(lane, C::NL) : lane;
+    const bool own = C::kDummy || lane < C::NL;  // (values of the other lanes never reach a valid output)
     const int H = g.H, W = g.W;
     const int x_lo = blockIdx.x * NV;
     const int y_lo = blockIdx.y * g.band, y_hi = min(H, y_lo + g.band);
@@ -370,18 +375,26 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
         double2 lv0 = make_double2(0.0, 0.0), lv1 = lv0;
         if (do2 && !init2) {  // leaving a/b row y2-1-a = r1-RC: read before its slot is overwritten by row r1
             const int ls = STEADY ? wslot : reflect_clamp(y2 - 1 - a, H) % RC;
-            lv0 = ring[(ls * 2 + 0) * NLp + rl];
-            lv1 = ring[(ls * 2 + 1) * NLp + rl];
+            if (own) {
+                lv0 = ring[(ls * 2 + 0) * NLp + rl];
+                lv1 = ring[(ls * 2 + 1) * NLp + rl];
+            }
         }
         if (do1) {
-            ring[(wslot * 2 + 0) * NLp + rl] = make_double2(av[0], bv[0]);
-            ring[(wslot * 2 + 1) * NLp + rl] = make_double2(av[1], bv[1]);
+            if (own) {
+                ring[(wslot * 2 + 0) * NLp + rl] = make_double2(av[0], bv[0]);
+                ring[(wslot * 2 + 1) * NLp + rl] = make_double2(av[1], bv[1]);
+            }
         }
         if (do2) {
             if (init2) {
                 for (int j = 0; j < K; ++j) {
                     const int rs = reflect_clamp(y_lo - a + j, H) % RC;
-                    const double2 e0 = ring[(rs * 2 + 0) * NLp + rl], e1 = ring[(rs * 2 + 1) * NLp + rl];
+                    double2 e0 = make_double2(0.0, 0.0), e1 = e0;
+                    if (own) {
+                        e0 = ring[(rs * 2 + 0) * NLp + rl];
+                        e1 = ring[(rs * 2 + 1) * NLp + rl];
+                    }
                     V2[0][0] += e0.x; V2[1][0] += e0.y;
                     V2[0][1] += e1.x; V2[1][1] += e1.y;
                 }
@@ -393,8 +406,11 @@ __global__ void __launch_bounds__(64, WPE) k_guided_wave(const uint8_t *__restri
                     e1 = make_double2(av[1], bv[1]);
                 } else {
                     const int es = STEADY ? pslot : er % RC;
-                    e0 = ring[(es * 2 + 0) * NLp + rl];
-                    e1 = ring[(es * 2 + 1) * NLp + rl];
+                    e0 = e1 = make_double2(0.0, 0.0);
+                    if (own) {
+                        e0 = ring[(es * 2 + 0) * NLp + rl];
+                        e1 = ring[(es * 2 + 1) * NLp + rl];
+                    }
                 }
                 V2[0][0] += e0.x - lv0.x; V2[1][0] += e0.y - lv0.y;
                 V2[0][1] += e1.x - lv1.x; V2[1][1] += e1.y - lv1.y;
