@@ -1,3 +1,5 @@
+"""Timings of the SURVEY 8f entry points (features, quality scores, differentiable enhancement, six-strategy fan-out) at
+4K x 16.  Run on the GPU box from the repo root: python profiles/time_next_rows.py"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

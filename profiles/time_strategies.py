@@ -1,3 +1,5 @@
+"""Per-strategy timings at 4K x 16 with the six largest kernels of each (both surfaces).  Run on the GPU box from the repo
+root: python profiles/time_strategies.py"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
