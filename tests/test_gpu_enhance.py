@@ -320,11 +320,11 @@ def test_select_paths_agree(uw, orc, monkeypatch):
                 monkeypatch.setenv("UWIE_SELECT_GENERIC", "1")
                 check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
                 monkeypatch.delenv("UWIE_SELECT_GENERIC")
-                if k != 3:  # the producer files predicted windows for strategies 1-2: off, still covering, missing
-                    for knob, val in (("UWIE_LIN_NO_PREDICT", "1"), ("UWIE_LIN_PREDICT_SHIFT", "2"), ("UWIE_LIN_PREDICT_SHIFT", "400")):
-                        monkeypatch.setenv(knob, val)
-                        check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
-                        monkeypatch.delenv(knob)
+                # the producer files the predicted windows (two, or strategy 3's four): off, still covering, missing
+                for knob, val in (("UWIE_LIN_NO_PREDICT", "1"), ("UWIE_LIN_PREDICT_SHIFT", "2"), ("UWIE_LIN_PREDICT_SHIFT", "400")):
+                    monkeypatch.setenv(knob, val)
+                    check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
+                    monkeypatch.delenv(knob)
         check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")
     monkeypatch.delenv("UWIE_RESTORE_STORE")
     batch = np.stack([noisy[:120, :200], flatish[:120, :200], noisy[30:150, 10:210]])

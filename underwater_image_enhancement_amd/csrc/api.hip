@@ -171,9 +171,10 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // 17.5 ms per step).
         const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call: the tests compare both modes
         recompute = k != 3 && !(env_store && atoi(env_store) == 1);
-        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, k != 3 ? &src : nullptr));
+        // (strategy 3 keeps the planes: its tail reads them; its four percentiles get four predicted windows)
+        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, &src));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
-                                            k != 3 ? &plan : nullptr));
+                                            &plan));
         UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
     }
     if (k == 3) {

@@ -240,10 +240,11 @@ struct LinState {
     uint32_t gbin[2 * kMaxPct];  // bin of the collecting sweep's group g (list g)
     uint32_t gcount[kLinLists];  // elements filed in each list
     uint32_t ngroups;            // groups the collecting sweep has to fill (0: the prediction covered every query)
-    uint32_t wlo[2], wspan[2];   // predicted windows: bins wlo .. wlo + wspan (wlo = kLinNoWin: none), list = window
+    uint32_t wlo[kMaxPct], wspan[kMaxPct];  // predicted windows (one per percentile, merged when they touch): bins
+                                            // wlo .. wlo + wspan (wlo = kLinNoWin: none), list = window
 };
 struct RestoreSrc;
-// predict != nullptr (nq <= 2): the target bins are predicted from a subsample of the restored image (k_lin_sample)
+// predict != nullptr: the target bins are predicted from a subsample of the restored image (k_lin_sample)
 int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
                      const RestoreSrc *predict = nullptr);
 // src != nullptr: the values are recomputed from *src; d_planar is then only written (and read back) for planes that

@@ -28,18 +28,17 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 // grid (nblk, B), block 256.  LIN: the histogram is over lin_digit() (select_lin_*), else over the top 11 key bits.
 // planar == nullptr: histogram only (the consumers recompute the image from S, restore.h); ghist == nullptr: image
 // only; only != nullptr: images none of whose three planes is flagged are skipped.
-// COLLECT (with LIN): values whose digit lies in one of the plane's two predicted windows (LinState::wlo, wspan) are
-// filed into the window's list on the way: staged in LDS, moved out in batches (a block reserves list space once per
-// batch and window).
-constexpr int kWinStage = 256;
-template <bool LIN, bool COLLECT>
+// COLLECT (with LIN): values whose digit lies in one of the plane's NW predicted windows (LinState::wlo, wspan; two for
+// two percentiles, four for strategy 3's four) are filed into the window's list on the way: staged in LDS, moved out in
+// batches (a block reserves list space once per batch and window).
+template <bool LIN, bool COLLECT, int NW = 2>
 __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist,
                                                              const uint32_t *__restrict__ only, LinState *__restrict__ lin,
                                                              float *__restrict__ lists, uint32_t cap)
 {
     constexpr int NB = LIN ? 2052 : 2048;
-    constexpr int NS = COLLECT ? 6 : 1, SN = COLLECT ? kWinStage : 1;
+    constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 ? 256 : 128) : 1;  // 6 KB of stages either way
     __shared__ uint32_t h[3][NB];
     __shared__ float stg[NS][SN];
     __shared__ uint32_t scount[NS], sbase[NS];
@@ -54,17 +53,18 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     __syncthreads();
     float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
-    // COLLECT: the top two bits of a bin's LDS counter say which window (1, 2) the bin belongs to, so the histogram
+    // COLLECT: the top bits of a bin's LDS counter say which window (1 .. NW) the bin belongs to, so the histogram
     // atomic's return value tells whether the value is a candidate: no separate window test per value
-    constexpr uint32_t kCntMask = 0x3fffffffu;
+    constexpr int kFlagShift = NW == 2 ? 30 : 29;
+    constexpr uint32_t kCntMask = (1u << kFlagShift) - 1u;
     if (COLLECT) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const uint32_t lo = lin[3 * b + c].wlo[w], span = lin[3 * b + c].wspan[w];
                 if (lo != kLinNoWin)
-                    for (uint32_t i = tid; i <= span; i += 256) h[c][lo + i] = (uint32_t)(w + 1) << 30;
+                    for (uint32_t i = tid; i <= span; i += 256) h[c][lo + i] = (uint32_t)(w + 1) << kFlagShift;
             }
         __syncthreads();
     }
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         ++run[c];
     };
     auto file = [&](int c, int w, float x) {  // x is a candidate of window w of channel c
-        const int j = c * 2 + w;
+        const int j = c * NW + w;
         const uint32_t pos = atomicAdd(&scount[j], 1u);
         if (pos < (uint32_t)SN) {
             stg[j][pos] = x;
@@ -98,12 +98,12 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         if (!need) return;  // block-uniform
         if (tid < NS) {
             const uint32_t c = min(scount[tid], (uint32_t)SN);
-            if (c) sbase[tid] = atomicAdd(&lin[3 * b + (tid >> 1)].gcount[tid & 1], c);
+            if (c) sbase[tid] = atomicAdd(&lin[3 * b + tid / NW].gcount[tid % NW], c);
         }
         __syncthreads();
         for (int j = 0; j < NS; ++j) {
             const uint32_t c = min(scount[j], (uint32_t)SN), base = sbase[j];
-            float *L = lists + ((size_t)(3 * b + (j >> 1)) * kLinLists + (j & 1)) * cap;
+            float *L = lists + ((size_t)(3 * b + j / NW) * kLinLists + (j % NW)) * cap;
             for (uint32_t i = tid; i < c; i += 256)
                 if (base + i < cap) L[base + i] = stg[j][i];
         }
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            if (old[c][i] >> 30) file(c, (int)(old[c][i] >> 30) - 1, r[c][i]);
+                            if (old[c][i] >> kFlagShift) file(c, (int)(old[c][i] >> kFlagShift) - 1, r[c][i]);
                 }
             } else if (ghist) {
 #pragma unroll
@@ -828,13 +828,18 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     if (nblk > need) nblk = need;
     const RestoreSrc S{d_in, d_kind, d_A, d_t};
     const dim3 grid(nblk, s.B);
-    const auto k_restore_hist_collect = k_restore_planar_hist<true, true>;  // (names as the profiler reports them)
+    const auto k_restore_hist_collect = k_restore_planar_hist<true, true, 2>;  // (names as the profiler reports them)
+    const auto k_restore_hist_collect4 = k_restore_planar_hist<true, true, 4>;
     const auto k_restore_hist_lin = k_restore_planar_hist<true, false>;
     const auto k_restore_hist_key = k_restore_planar_hist<false, false>;
     if (plan) {
         UWIE_REQUIRE(linear && d_ghist == plan->ghist, "restore: a selection plan goes with its own linear histogram");
-        UWIE_LAUNCH(k_restore_hist_collect, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
-                    (LinState *)plan->lin, plan->lists, plan->cap);
+        if (plan->nq <= 2)
+            UWIE_LAUNCH(k_restore_hist_collect, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                        (LinState *)plan->lin, plan->lists, plan->cap);
+        else
+            UWIE_LAUNCH(k_restore_hist_collect4, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                        (LinState *)plan->lin, plan->lists, plan->cap);
     } else if (linear) {
         UWIE_LAUNCH(k_restore_hist_lin, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
                     (LinState *)nullptr, (float *)nullptr, 0u);

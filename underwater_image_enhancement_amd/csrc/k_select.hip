@@ -463,14 +463,14 @@ __global__ void __launch_bounds__(256) k_lin_sample(RestoreSrc S, int npx, int s
 __global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
                                                      RankList ranks, uint32_t n, uint32_t ns, int shift)
 {
-    __shared__ uint32_t h[kLinBins], wsum[4], found[2], wl[2], wh[2];
+    __shared__ uint32_t h[kLinBins], wsum[4], found[2], wl[kMaxPct], wh[kMaxPct];
     const int bc = blockIdx.x, tid = threadIdx.x;
-    if (tid < 2) { wl[tid] = kLinNoWin; wh[tid] = 0; }
+    if (tid < kMaxPct) { wl[tid] = kLinNoWin; wh[tid] = 0; }
     if (ns > 0) {
         const uint32_t *gh = ghist + (size_t)bc * kSelGroupStride + kLinSampleOff;
         for (int i = tid; i < kLinBins; i += 256) h[i] = gh[i];
         __syncthreads();
-        for (int j = 0; j < ranks.n / 2 && j < 2; ++j) {
+        for (int j = 0; j < ranks.n / 2 && j < kMaxPct; ++j) {
             const double p = (double)ranks.r[2 * j] / (double)n, sd = sqrt((double)ns * p * (1.0 - p));
             const double c0 = (double)ranks.r[2 * j] * ns / n, c1 = (double)ranks.r[2 * j + 1] * ns / n, delta = 4.0 * sd + 2.0;
             const uint32_t rlo = (uint32_t)fmax(c0 - delta, 0.0), rhi = (uint32_t)fmin(c1 + delta, (double)ns - 1.0);
@@ -489,12 +489,19 @@ __global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, 
         for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.qbin[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; }
         for (int g = 0; g < kLinLists; ++g) s.gcount[g] = 0;
         s.ngroups = 0;
-        if (wl[0] != kLinNoWin && wl[1] != kLinNoWin && wl[1] <= wh[0] + 1) {  // touching windows: one
-            wh[0] = max(wh[0], wh[1]);
-            wl[0] = min(wl[0], wl[1]);
-            wl[1] = kLinNoWin;
+        // windows that touch or overlap become one (the producer files a value under one window only)
+        for (bool again = true; again;) {
+            again = false;
+            for (int i = 0; i < kMaxPct; ++i)
+                for (int j = i + 1; j < kMaxPct; ++j)
+                    if (wl[i] != kLinNoWin && wl[j] != kLinNoWin && wl[j] <= wh[i] + 1 && wl[i] <= wh[j] + 1) {
+                        wl[i] = min(wl[i], wl[j]);
+                        wh[i] = max(wh[i], wh[j]);
+                        wl[j] = kLinNoWin;
+                        again = true;
+                    }
         }
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < kMaxPct; ++w) {
             s.wlo[w] = wl[w];
             s.wspan[w] = wl[w] == kLinNoWin ? 0 : wh[w] - wl[w];
         }
@@ -533,8 +540,8 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
                 continue;
             }
             int w = -1;
-            if (qbin[q] - s.wlo[0] <= s.wspan[0]) w = 0;
-            else if (qbin[q] - s.wlo[1] <= s.wspan[1]) w = 1;
+            for (int i = kMaxPct - 1; i >= 0; --i)
+                if (qbin[q] - s.wlo[i] <= s.wspan[i]) w = i;
             if (w >= 0 && s.gcount[w] > cap) w = -1;  // the window met a heavy bin: the target bin alone may still fit
             if (w >= 0) s.gid[q] = (uint32_t)w;
             else covered = false;
@@ -833,7 +840,7 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
     const char *env_np = getenv("UWIE_LIN_NO_PREDICT"), *env_sh = getenv("UWIE_LIN_PREDICT_SHIFT");
     const int shift = env_sh ? atoi(env_sh) : 0;
     plan->predicted = false;
-    if (predict && nq <= 2 && !(env_np && atoi(env_np) == 1)) {
+    if (predict && !(env_np && atoi(env_np) == 1)) {
         plan->predicted = true;
         // ~128 K sample pixels per frame in evenly spaced groups of four (odd stride: no column is favoured): the
         // sampling error of a 1 % rank is ~0.03 % of the frame, half a bin where the 2048 bins are equally full
