@@ -1,0 +1,38 @@
+"""One-off randomised check on the GPU box: random frames x random strategy (both surfaces) x random test-knob set against the
+oracle; prints every case that differs.  SEED / N from the environment.  python profiles/fuzz_knobs.py"""
+import os, sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np
+import underwater_image_enhancement_amd as uw
+from oracle import uwie_oracle as orc
+from test_gpu_fuzz import random_frame
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+KNOBS = [{}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_LIN_NO_PREDICT": "1"}, {"UWIE_LIN_PREDICT_SHIFT": "3"}, {"UWIE_LIN_CAP": "24"},
+         {"UWIE_LIN_PREDICT_SHIFT": "300", "UWIE_RESTORE_STORE": "1"}, {"UWIE_SELECT_GENERIC": "1"}, {"UWIE_STREAMS": "2"}]
+ES = orc.DictStrategyOracle
+names = ["strong_dehazing", "medium_dehazing", "light_enhancement", "clahe_enhancement", "histogram_equalization"]
+bad = tot = 0
+for i in range(int(os.environ.get("N", "150"))):
+    u8 = random_frame(rng)
+    knobs = KNOBS[rng.integers(len(KNOBS))]
+    for k, v in knobs.items(): os.environ[k] = v
+    try:
+        if rng.random() < 0.7:
+            k = int(rng.integers(1, 7))
+            got, want = uw.enhance(u8, strategy=k), orc.enhance_u8(u8, k)
+            what = f"six {k}"
+        else:
+            name = names[rng.integers(5)]
+            x = orc.normalise_u8(u8)
+            # (float32 copies of the reference's float64 image: equal bit for bit without gamma, as in the tests)
+            want = ES.run(x, name, {}).astype(np.float32).view(np.uint32)
+            got = uw.EnhancementStrategies.apply_strategy(x, name, {}).view(np.uint32)
+            what = name
+    finally:
+        for k in knobs: del os.environ[k]
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    tot += 1
+    if d.max() > 0:
+        bad += 1
+        print("DIFF", i, u8.shape, what, knobs, "max", d.max(), "count", int((d > 0).sum()))
+print("cases", tot, "with differences", bad)
