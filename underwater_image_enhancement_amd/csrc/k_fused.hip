@@ -823,7 +823,8 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
     static const char *env_nb = getenv("UWIE_RESTORE_BLOCKS");
     int nblk = env_nb ? atoi(env_nb) : cdiv(12288, s.B);  // 4K x 64: 32 per frame 2.79 ms, 96: 2.52, 192: 2.43, 384: 2.47
-    nblk = nblk < 16 ? 16 : nblk > 1024 ? 1024 : nblk;
+    // (a block clears and flushes 6 K counters: small batches get fewer, longer blocks; 4K x 16: 768 per frame 0.62 ms, 192: 0.53)
+    nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     const RestoreSrc S{d_in, d_kind, d_A, d_t};
@@ -855,7 +856,7 @@ int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const do
                                  uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only)
 {
     int nblk = cdiv(12288, s.B);
-    nblk = nblk < 16 ? 16 : nblk > 1024 ? 1024 : nblk;
+    nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     const RestoreSrc S{d_in, nullptr, d_A, d_t};
