@@ -24,6 +24,7 @@
 #include "common.h"
 #include "devutil.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -476,6 +477,12 @@ int launch_wave(const uint8_t *d_gray, const float *d_t0, Shape s, double eps, d
         // ~12 wavefronts per resident slot evens out the tail (4K x 64, k = 15: 1 band 6.44 ms, 2: 6.01, 6: 5.89, 16: 6.22;
         // every band pays 2(k-1) extra rows and a start-up sum)
         if (strips < 12L * resident) nbands = (int)cdiv((size_t)(12L * resident), (size_t)strips);
+        // ... but a band should be at least eight times its 2(k-1) overlap rows long: small batches would otherwise be
+        // cut into many short bands (4K x 16, k = 15: 25 bands 1.59 ms, 8 bands 1.47 ms)
+        // -- as long as that still leaves three wavefronts per resident slot (a single 1080p frame needs all the bands
+        // it can get)
+        const int cap = std::max(1, s.H / (16 * (K - 1)));
+        nbands = std::min(nbands, std::max(cap, (int)cdiv((size_t)(3L * resident), (size_t)strips)));
     }
     nbands = max(1, min(nbands, s.H / max(64, 4 * K)));
     WaveGeom g;
