@@ -114,6 +114,59 @@ struct StretchDiv {
     __device__ __forceinline__ float quot_unit(float n) const { return fast ? seq(n) : n / den; }
 };
 
+// x**g for float32 operands (np.power / torch.pow on float32 data) where it is evaluated per pixel: float64
+// exp2(g * log2(x)) with x = m * 2^e, m in [sqrt(1/2), sqrt(2)): log(m) = 2 atanh((m-1)/(m+1)) by its series to t^19
+// (truncation 2^-50), exp2 of the fraction by its Taylor polynomial of degree 12 (2^-52), so the value is good to ~2^-46
+// and its float32 rounding is the exact power's except about once per million arguments (then the neighbouring float).
+// The library pow() this replaces costs about four times as many instructions; the reference's own powf is only
+// faithfully rounded, so the contract (<= 1 float32 ulp against it, written in the tests) is unchanged.  Arguments
+// outside 2^-126 <= x <= 16, 0 < g <= 64 take pow().
+__device__ __forceinline__ float pow_f32_fast(float x, float g)
+{
+    if (!(x >= 0x1p-126f && x <= 16.0f && g > 0.0f && g <= 64.0f)) return (float)pow((double)x, (double)g);
+    const uint32_t bits = __float_as_uint(x);
+    int e = (int)(bits >> 23) - 127;
+    float mf = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u);  // [1, 2)
+    if (mf > 1.41421356f) {
+        mf *= 0.5f;
+        e += 1;
+    }
+    const double m = (double)mf, d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double t = (m - 1.0) * r, t2 = t * t;
+    double p = 1.0 / 19.0;
+    p = fma(p, t2, 1.0 / 17.0);
+    p = fma(p, t2, 1.0 / 15.0);
+    p = fma(p, t2, 1.0 / 13.0);
+    p = fma(p, t2, 1.0 / 11.0);
+    p = fma(p, t2, 1.0 / 9.0);
+    p = fma(p, t2, 1.0 / 7.0);
+    p = fma(p, t2, 1.0 / 5.0);
+    p = fma(p, t2, 1.0 / 3.0);
+    p = fma(p, t2, 1.0);
+    const double lg2 = fma(2.8853900817779268 * t, p, (double)e);  // log2(x)
+    const double y = (double)g * lg2;
+    if (y < -160.0) return 0.0f;  // below the smallest float32 subnormal
+    const double n = rint(y), f = y - n;
+    double q = 2.5678435993488206e-11;
+    q = fma(q, f, 4.4455382718708116e-10);
+    q = fma(q, f, 7.054911620801123e-09);
+    q = fma(q, f, 1.01780860092397e-07);
+    q = fma(q, f, 1.321548679014431e-06);
+    q = fma(q, f, 1.5252733804059841e-05);
+    q = fma(q, f, 0.0001540353039338161);
+    q = fma(q, f, 0.0013333558146428443);
+    q = fma(q, f, 0.009618129107628477);
+    q = fma(q, f, 0.05550410866482158);
+    q = fma(q, f, 0.24022650695910072);
+    q = fma(q, f, 0.6931471805599453);
+    q = fma(q, f, 1.0);
+    const double v = __longlong_as_double(__double_as_longlong(q) + (long long)n * (1ll << 52));  // q * 2^n, |n| <= 256
+    return (float)v;
+}
+
 // which channel color_correction attenuates for a cast kind (UWIE_CAST_*): greenish -> G, bluish -> B
 __device__ __forceinline__ bool px_atten(int kind, int c) { return kind != 0 && c == kind; }
 // (img * 255).astype(np.uint8): float32 product, truncation toward zero

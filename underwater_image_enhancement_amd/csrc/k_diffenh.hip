@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_diff_enhance(const float *__restrict__ 
         }
         if (flags & 2) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[c] = (float)pow((double)(v[c] + 1e-8f), (double)gamma);
+            for (int c = 0; c < 3; ++c) v[c] = pow_f32_fast(v[c] + 1e-8f, gamma);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_gamma(const float *__restrict__ img, fl
                                                int clip)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = pow_f32(img[i], g);
+        float v = pow_f32_fast(img[i], g);
         if (clip) v = fminf(fmaxf(v, 0.0f), 1.0f);
         out[i] = v;
     }
