@@ -129,7 +129,8 @@ def test_dict_surface_matches_oracle(uw, orc, name):
 
 def test_dict_surface_select_and_store_modes(uw, orc, monkeypatch):
     """The dict surface's dehazing strategies take their float64 percentiles from the linear-digit selection on an image
-    that is recomputed per sweep (default); the stored-plane mode, the forced fallback to the generic key sweeps (tiny
+    that is recomputed per sweep, with the target bins predicted from a sample (default); prediction off or missing,
+    the stored-plane mode, the forced fallback to the generic key sweeps (tiny
     candidate lists: flagged planes are written out first) and the generic sweeps alone must give the same floats."""
     rng = np.random.default_rng(515)
     noisy = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
@@ -143,7 +144,8 @@ def test_dict_surface_select_and_store_modes(uw, orc, monkeypatch):
             x = orc.normalise_u8(u8)
             want = ES.run(x, name, {}).astype(np.float32)
             for env in ({}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_LIN_CAP": "16"}, {"UWIE_LIN_CAP": "16", "UWIE_RESTORE_STORE": "1"},
-                        {"UWIE_SELECT_GENERIC": "1"}):
+                        {"UWIE_SELECT_GENERIC": "1"}, {"UWIE_LIN_NO_PREDICT": "1"}, {"UWIE_LIN_PREDICT_SHIFT": "400"},
+                        {"UWIE_LIN_PREDICT_SHIFT": "400", "UWIE_RESTORE_STORE": "1"}):
                 for k, v in env.items():
                     monkeypatch.setenv(k, v)
                 got = uw.EnhancementStrategies.apply_strategy(x, name, {})

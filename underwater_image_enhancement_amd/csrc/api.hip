@@ -225,8 +225,9 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
         // UWIE_RESTORE_STORE=1 keeps the stored planes.
         const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call
         recompute = !(env_store && atoi(env_store) == 1);
-        UWIE_TRY(select_lin_begin64(s, q, 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, recompute ? nullptr : P.F64, plan.ghist, st, true));
+        UWIE_TRY(select_lin_begin64(s, q, 2, P.scratch, st, &plan, &src));
+        UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, recompute ? nullptr : P.F64, plan.ghist, st, true, nullptr,
+                                              &plan));
         UWIE_TRY(select_lin_run64(plan, P.F64, s, st, recompute ? &src : nullptr));
     }
     UWIE_TRY(select_lerp64(plan, s, P.pct64, st));

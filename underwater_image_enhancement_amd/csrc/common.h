@@ -251,7 +251,8 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
 // fall back to the generic sweeps
 int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc *src = nullptr);
 // float64 planes (ES surface): linear first digit by the producer, one collecting sweep, finish on the lists
-int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
+int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
+                       const RestoreSrc *predict = nullptr);
 int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStream_t st, const RestoreSrc *src = nullptr);
 int select_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan);
 int select_run(const SelectPlan &plan, const float *d_vals, int planar, Shape s, bool pass1_done, hipStream_t st);
@@ -294,7 +295,8 @@ int launch_tail_plain(const float *d_planar, const float *d_pct, int pct_stride,
 // ES surface (float64): recover_image (ES:237-249) -> planar float64 + first select digit; color_enhancement
 // (ES:269-270, eps 1e-10) [-> gamma_correction (ES:284-285)] -> (y*255).astype(u8) (main.py:155) / float32 copy
 int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
-                                 uint32_t *d_ghist, hipStream_t st, bool linear = false, const uint32_t *d_only = nullptr);
+                                 uint32_t *d_ghist, hipStream_t st, bool linear = false, const uint32_t *d_only = nullptr,
+                                 const SelectPlan *plan = nullptr);
 int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
                         uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src = nullptr);
 

@@ -31,16 +31,18 @@ __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0)
 // COLLECT (with LIN): values whose digit lies in one of the plane's NW predicted windows (LinState::wlo, wspan; two for
 // two percentiles, four for strategy 3's four) are filed into the window's list on the way: staged in LDS, moved out in
 // batches (a block reserves list space once per batch and window).
-template <bool LIN, bool COLLECT, int NW = 2>
-__global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, float *__restrict__ planar,
+// V = double: the ES surface's float64 image (restore.h four64), float64 planes and lists.
+template <bool LIN, bool COLLECT, int NW = 2, typename V = float>
+__global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int npx, V *__restrict__ planar,
                                                              uint32_t *__restrict__ ghist,
                                                              const uint32_t *__restrict__ only, LinState *__restrict__ lin,
-                                                             float *__restrict__ lists, uint32_t cap)
+                                                             V *__restrict__ lists, uint32_t cap)
 {
     constexpr int NB = LIN ? 2052 : 2048;
-    constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 ? 256 : 128) : 1;  // 6 KB of stages either way
+    constexpr bool F64 = sizeof(V) == 8;
+    constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 && !F64 ? 256 : 128) : 1;  // 6 KB of stages (12: float64, NW 4)
     __shared__ uint32_t h[3][NB];
-    __shared__ float stg[NS][SN];
+    __shared__ V stg[NS][SN];
     __shared__ uint32_t scount[NS], sbase[NS];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     RestoreImgT<false> R;
     R.init(S, b, (size_t)npx);
     __syncthreads();
-    float *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
+    V *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
     // COLLECT: the top bits of a bin's LDS counter say which window (1 .. NW) the bin belongs to, so the histogram
     // atomic's return value tells whether the value is a candidate: no separate window test per value
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         }
         ++run[c];
     };
-    auto file = [&](int c, int w, float x) {  // x is a candidate of window w of channel c
+    auto file = [&](int c, int w, V x) {  // x is a candidate of window w of channel c
         const int j = c * NW + w;
         const uint32_t pos = atomicAdd(&scount[j], 1u);
         if (pos < (uint32_t)SN) {
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         __syncthreads();
         for (int j = 0; j < NS; ++j) {
             const uint32_t c = min(scount[j], (uint32_t)SN), base = sbase[j];
-            float *L = lists + ((size_t)(3 * b + j / NW) * kLinLists + (j % NW)) * cap;
+            V *L = lists + ((size_t)(3 * b + j / NW) * kLinLists + (j % NW)) * cap;
             for (uint32_t i = tid; i < c; i += 256)
                 if (base + i < cap) L[base + i] = stg[j][i];
         }
@@ -116,8 +118,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         const int p = it * step + (blockIdx.x * 256 + tid) * 4;
         const int n = min(4, npx - p);
         if (n > 0) {
-            float r[3][4];
-            R.four(p, n, r);
+            V r[3][4];
+            if constexpr (F64) R.four64(p, n, r);
+            else R.four(p, n, r);
             if (ghist && LIN) {
                 // all twelve histogram atomics first, their return values (window flags) afterwards: one LDS round trip
                 uint32_t old[3][4];
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         // r is clipped to [0, 1]: lin_digit(x) == (uint)(x * 2048) + (x > 0)
-                        const uint32_t d = (uint32_t)(r[c][i] * 2048.0f) + (r[c][i] > 0.0f ? 1u : 0u);
+                        const uint32_t d = (uint32_t)(r[c][i] * (V)2048) + (r[c][i] > (V)0 ? 1u : 0u);
                         const bool live = i < n;
                         sat0[c] += live && d == 0;
                         sat1[c] += live && d == (uint32_t)kLinBins - 1;
@@ -144,12 +147,30 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
                 for (int i = 0; i < 4; ++i) {
                     if (i < n) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) bump(c, f32_key(r[c][i]) >> 21);
+                        for (int c = 0; c < 3; ++c) {
+                            if constexpr (F64) bump(c, (uint32_t)(f64_key(r[c][i]) >> 53));
+                            else bump(c, f32_key(r[c][i]) >> 21);
+                        }
                     }
                 }
             }
             if (planar) {
-                if (aligned && n == 4) {
+                if constexpr (F64) {
+                    if (aligned && n == 4) {  // (npx a multiple of 4: plane rows of two doubles are 16-byte aligned)
+                        V *o[3] = {o0, o1, o2};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            *reinterpret_cast<double2 *>(o[c] + p) = make_double2(r[c][0], r[c][1]);
+                            *reinterpret_cast<double2 *>(o[c] + p + 2) = make_double2(r[c][2], r[c][3]);
+                        }
+                    } else {
+                        for (int i = 0; i < n; ++i) {
+                            o0[p + i] = r[0][i];
+                            o1[p + i] = r[1][i];
+                            o2[p + i] = r[2][i];
+                        }
+                    }
+                } else if (aligned && n == 4) {
                     *reinterpret_cast<float4 *>(o0 + p) = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
                     *reinterpret_cast<float4 *>(o1 + p) = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
                     *reinterpret_cast<float4 *>(o2 + p) = make_float4(r[2][0], r[2][1], r[2][2], r[2][3]);
@@ -669,55 +690,7 @@ __global__ void __launch_bounds__(256) k_stretch_out(const float *__restrict__ p
 
 // ---- ES surface, float64
 // recovered = clip((img - A) / t + A, 0, 1): float32 difference, float64 quotient/sum/result (ES:247-248)
-// LIN: the histogram is over lin_digit() (select_lin_*64), else over the top 11 key bits.  planar == nullptr: histogram
-// only (the consumers recompute the image, restore.h four64); ghist == nullptr: image only; only != nullptr: images none
-// of whose planes is flagged are skipped.  Four pixels per thread.
-template <bool LIN>
-__global__ void __launch_bounds__(256) k_recover64_planar_hist(RestoreSrc S, int npx, double *__restrict__ planar,
-                                                               uint32_t *__restrict__ ghist,
-                                                               const uint32_t *__restrict__ only)
-{
-    constexpr int NB = LIN ? 2052 : 2048;
-    __shared__ uint32_t h[3][NB];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
-    if (ghist) {
-        for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
-        __syncthreads();
-    }
-    RestoreImg R;
-    R.init(S, b, (size_t)npx);
-    double *o[3] = {planar + (size_t)b * 3 * npx, planar + (size_t)b * 3 * npx + npx, planar + (size_t)b * 3 * npx + 2 * (size_t)npx};
-    const bool aligned = (npx & 1) == 0;  // plane rows of two doubles are 16-byte aligned
-    for (int p = (blockIdx.x * 256 + tid) * 4; p < npx; p += gridDim.x * 1024) {
-        const int n = min(4, npx - p);
-        double r[3][4];
-        R.four64(p, n, r);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (planar) {
-                if (aligned && n == 4) {
-                    *reinterpret_cast<double2 *>(o[c] + p) = make_double2(r[c][0], r[c][1]);
-                    *reinterpret_cast<double2 *>(o[c] + p + 2) = make_double2(r[c][2], r[c][3]);
-                } else {
-                    for (int i = 0; i < n; ++i) o[c][p + i] = r[c][i];
-                }
-            }
-            if (ghist) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < n) atomicAdd(&h[c][LIN ? lin_digit(r[c][i]) : (uint32_t)(f64_key(r[c][i]) >> 53)], 1u);
-            }
-        }
-    }
-    if (!ghist) return;
-    __syncthreads();
-    for (int i = tid; i < 3 * NB; i += 256) {
-        const uint32_t c = (&h[0][0])[i];
-        if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / NB) * kSelGroupStride + (i % NB)], c);
-    }
-}
-
+// (recovered = clip((img - A) / t + A, 0, 1) in float64, ES:247-248: k_restore_planar_hist<..., double>)
 // pct: [B][3][2] float64 = lo, hi.  grid (n, B), four pixels per thread.  SRC: the recovered image is recomputed from S
 // instead of read from planar.  The three stretch quotients of a channel share the denominator: the float64 division's
 // own sequence with the reciprocal kept (as restore.h does for the divisor t), true division outside its safe range.
@@ -853,19 +826,28 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 }
 
 int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const double *d_t, Shape s, double *d_planar,
-                                 uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only)
+                                 uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only, const SelectPlan *plan)
 {
     int nblk = cdiv(12288, s.B);
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
     const RestoreSrc S{d_in, nullptr, d_A, d_t};
-    const auto k_recover64_hist_lin = k_recover64_planar_hist<true>;  // (names as the profiler reports them)
-    const auto k_recover64_hist_key = k_recover64_planar_hist<false>;
-    if (linear)
-        UWIE_LAUNCH(k_recover64_hist_lin, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only);
-    else
-        UWIE_LAUNCH(k_recover64_hist_key, dim3(nblk, s.B), dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only);
+    const dim3 grid(nblk, s.B);
+    const auto k_recover64_hist_collect = k_restore_planar_hist<true, true, 2, double>;  // (names as the profiler reports them)
+    const auto k_recover64_hist_lin = k_restore_planar_hist<true, false, 2, double>;
+    const auto k_recover64_hist_key = k_restore_planar_hist<false, false, 2, double>;
+    if (plan) {
+        UWIE_REQUIRE(linear && d_ghist == plan->ghist && plan->nq <= 2, "recover: a selection plan goes with its own linear histogram");
+        UWIE_LAUNCH(k_recover64_hist_collect, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
+                    (LinState *)plan->lin, reinterpret_cast<double *>(plan->lists), plan->cap);
+    } else if (linear) {
+        UWIE_LAUNCH(k_recover64_hist_lin, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only, (LinState *)nullptr,
+                    (double *)nullptr, 0u);
+    } else {
+        UWIE_LAUNCH(k_recover64_hist_key, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only, (LinState *)nullptr,
+                    (double *)nullptr, 0u);
+    }
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

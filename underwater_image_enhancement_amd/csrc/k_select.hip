@@ -434,6 +434,7 @@ constexpr int kLinSampleOff = 4096;  // the sample histogram of a plane lives be
 
 // grid (blocks, B): linear-digit histogram of the restored image on every stride-th group of four pixels (ngs groups;
 // the frame as one flat array, so the sample is spread over rows and columns alike)
+template <typename V>
 __global__ void __launch_bounds__(256) k_lin_sample(RestoreSrc S, int npx, int stride, int ngs, uint32_t *__restrict__ ghist)
 {
     __shared__ uint32_t h[3][kLinBins];
@@ -443,8 +444,9 @@ __global__ void __launch_bounds__(256) k_lin_sample(RestoreSrc S, int npx, int s
     RestoreImg R;
     R.init(S, b, (size_t)npx);
     for (int i = blockIdx.x * 256 + tid; i < ngs; i += gridDim.x * 256) {
-        float r[3][4];
-        R.four((i * stride + stride / 2) * 4, 4, r);
+        V r[3][4];
+        if constexpr (sizeof(V) == 8) R.four64((i * stride + stride / 2) * 4, 4, r);  // (ES surface: the float64 image)
+        else R.four((i * stride + stride / 2) * 4, 4, r);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -850,7 +852,7 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
             if (stride > 1) stride |= 1;
             const int ngs = ngroups / stride;
             ns = 4u * (uint32_t)ngs;
-            UWIE_LAUNCH(k_lin_sample, dim3(std::max(1, std::min(8, cdiv(ngs, 512))), s.B), dim3(256), 0, st, *predict, (int)n,
+            UWIE_LAUNCH(k_lin_sample<float>, dim3(std::max(1, std::min(8, cdiv(ngs, 512))), s.B), dim3(256), 0, st, *predict, (int)n,
                         stride, ngs, plan->ghist);
             UWIE_LAUNCH_CHECK();
         }
@@ -904,7 +906,8 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
 }
 
 // float64 planes (ES surface): the same selection without the prediction; the lists hold doubles
-int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan)
+int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
+                       const RestoreSrc *predict)
 {
     UWIE_REQUIRE(nq >= 1 && nq <= kMaxPct, "percentiles: 1..4 percentiles per call");
     const long long n = (long long)s.npx();
@@ -921,14 +924,29 @@ int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipSt
     plan->cap = lin_cap(s);
     plan->nq = nq;
     plan->is64 = true;
-    plan->predicted = false;
     for (int j = 0; j < nq; ++j)
         percentile_indices<double>(n, q_percent[j], &plan->ranks[2 * j], &plan->ranks[2 * j + 1], &plan->t[j]);
     UWIE_HIP_CHECK(hipMemsetAsync(plan->ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
     RankList ranks;
     ranks.n = 2 * nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan->ranks[j];
-    UWIE_LAUNCH(k_lin_predict, dim3(nbc), dim3(256), 0, st, (LinState *)plan->lin, plan->ghist, ranks, (uint32_t)n, 0u, 0);
+    // prediction as in select_lin_begin (same test knobs)
+    uint32_t ns = 0;
+    const char *env_np = getenv("UWIE_LIN_NO_PREDICT"), *env_sh = getenv("UWIE_LIN_PREDICT_SHIFT");
+    const int shift = env_sh ? atoi(env_sh) : 0;
+    plan->predicted = false;
+    const int ngroups = (int)(n / 4);
+    if (predict && nq <= 2 && ngroups > 0 && !(env_np && atoi(env_np) == 1)) {
+        plan->predicted = true;
+        int stride = std::max(1, ngroups / 32768);
+        if (stride > 1) stride |= 1;
+        const int ngs = ngroups / stride;
+        ns = 4u * (uint32_t)ngs;
+        UWIE_LAUNCH(k_lin_sample<double>, dim3(std::max(1, std::min(8, cdiv(ngs, 512))), s.B), dim3(256), 0, st, *predict, (int)n,
+                    stride, ngs, plan->ghist);
+        UWIE_LAUNCH_CHECK();
+    }
+    UWIE_LAUNCH(k_lin_predict, dim3(nbc), dim3(256), 0, st, (LinState *)plan->lin, plan->ghist, ranks, (uint32_t)n, ns, shift);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -947,6 +965,7 @@ int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStrea
     int blocks = (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
+    if (plan.predicted) blocks = std::max(1, std::min(2 * blocks, cdiv(24576, nbc)));  // (see select_lin_run)
     if (src) {
         const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
         const auto k_lin_collect_src64 = k_lin_collect_src<double, 4>;
