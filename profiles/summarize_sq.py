@@ -15,7 +15,7 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
         k = r["Kernel_Name"]
         if "uwie" not in k or flt not in k:
             continue
-        k = k.split("uwie::(anonymous namespace)::")[-1].split("(")[0][:48]
+        k = k.split("uwie::(anonymous namespace)::", 1)[-1].split("(")[0][:48]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
         if key not in seen:

@@ -108,7 +108,9 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
 int stage_guided(const Pipe &P, Shape s, const uwie_params *p, hipStream_t st)
 {
     int handled = 0;
-    if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st));
+    const char *env_ring = getenv("UWIE_GF_RING");  // read per call
+    const bool fx = p->surface == UWIE_SURFACE_SIX && env_ring && atoi(env_ring) == 1;
+    if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, fx));
     if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
     return UWIE_OK;
 }

@@ -179,8 +179,12 @@ int launch_guided_wave(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
                        hipStream_t st);
 bool guided_fast_handles(Shape s, int k);
 // k_guided_fast.hip: fused float64 guided filter (free summation order); *handled = 0 -> use launch_guided
+// ring_fx: the caller guarantees 0.1 <= t0 <= 1 (pre-clipped transmission) and accepts the fixed-point a/b ring
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
-                       hipStream_t st);
+                       hipStream_t st, bool ring_fx = false);
+// k_guided_pipe.hip: software-pipelined wavefront kernel for k in {10, 15, 20}; ring 0 = float64, 1 = fixed-point int32
+int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
+                       int *handled, hipStream_t st);
 
 // k_select.hip
 constexpr int kMaxPct = 4;  // percentiles per call

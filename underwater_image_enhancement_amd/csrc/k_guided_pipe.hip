@@ -1,0 +1,653 @@
+// guided_filter + clip (six_stadigy.py:26-46,178-180) as a software-pipelined wavefront kernel: the default path for the
+// reference's window widths (10, 15, 20: six_stadigy.py:234,245,255, config.py:29-53).
+//
+// Same decomposition as k_guided_wave.hip -- one autonomous wavefront owns 128 adjacent "slots" (two per lane) of a band
+// of rows and walks down one row per step, both box filters vertical-first with the horizontal window sums taken across
+// lanes through a wave-private LDS staging line, no workgroup barrier -- but the row's dependent chain
+//     raw rows -> vertical sums -> [LDS] -> window sums -> a, b -> ring -> vertical sums -> [LDS] -> window sums -> q
+// is cut at its two LDS round trips into three phases that run on three DIFFERENT rows in one step:
+//     step i:   C(i-2): window sums of V2 (staged by step i-1) -> q = mean_a*I + mean_b, clip -> HBM
+//               B(i-1): window sums of V1 (staged by step i-1) -> a, b -> V2 += ab(entering) - ab(leaving)
+//               A(i)  : V1 += raw(entering row) - raw(leaving row)
+//               -- all LDS reads of the step are issued first, all LDS writes (stagings of V1(i), V2(i-1), ring row i-1)
+//                  last, one compiler-only fence in between (LDS executes a wave's instructions in order) --
+// so a step's critical path is one LDS read plus the a/b arithmetic instead of the whole chain, and the three phases
+// give the scheduler independent instruction streams (the kernel is instruction-issue bound: profiles/microbench).
+//
+// Ring of a/b rows (k rows per slot, the only large per-strip state), two formats:
+//   RING_F64  float64 pairs, 16 B per slot and row (27 KB per strip at k = 15: five wavefronts per CU)
+//   RING_FX32 fixed point int32 pairs, 8 B per slot and row (14 KB: eight wavefronts per CU, two per SIMD).  a and b - b0
+//             are rounded ONCE to multiples of 2^-Sa / 2^-Sb when they enter the ring; every sum after that is exact
+//             (integers below 2^53 in float64), so the error of t is the mean of k*k independent roundings:
+//             |a| <= amax and |b - b0| <= 0.45 + amax follow from 0.1 <= p <= 1 (pre-clipped transmission, S6:174) and
+//             Cauchy-Schwarz, Sa/Sb are chosen so that |fixed| < 2^30: resolution 2^-31 .. 2^-32, error of t ~ 1e-11 rms.
+//             Only offered when the transmission is pre-clipped (six_stadigy surface).
+// Guide sums (sum g, sum g*g: exact integers) and sum p, sum g*p (float64, exact: multiples of 2^-27 below 2^26) as in
+// k_guided_wave.hip; a = cov/(var+eps) from the integer forms  var*(255 K^2)^2 = K^2*sum(gg) - sum(g)^2,
+// cov*255*K^4 = K^2*sum(gp) - sum(g)*sum(p), one Newton step on v_rcp_f64 (2^-23 -> 2^-46).
+// Same windows and borders as cv2.boxFilter (BORDER_REFLECT_101, anchor k/2); stated tolerance on t: 1e-11 (RING_F64),
+// 2e-10 (RING_FX32) -- tests/test_gpu_stages.py.
+#include "common.h"
+#include "devutil.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace uwie {
+
+namespace {
+
+constexpr int kPipeSlots = 128;
+constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: fma(x, s, kMagic) has round-to-nearest(x*s) in its low word
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PipeGeom {
+    int H, W, band;
+};
+
+struct PipeConsts {
+    double Ek;      // 255 * K^4 * eps
+    double fxa;     // 2^Sa                     (FX32)
+    double fxb;     // scale * 2^Sb             (FX32: b_fixed = lo32(fma(t3, fxb, magic_b)))
+    double magic_b; // kMagic - round(b0 * 2^Sb)
+    double kaI;     // mean_a * I = SA * kaI * g     (scale / 255 [/ 2^Sa])
+    double kb, b0;  // mean_b = SB * kb + b0
+};
+
+template <int K>
+struct PipeCfg {
+    static constexpr int a = K / 2, Lb = K - 1 - a, M = K / 2;
+    static constexpr int NV = kPipeSlots - 2 * (K - 1);   // output columns per strip
+    static constexpr int RC = 2 * a + 1;                  // ring rows
+    static constexpr int NL = (kPipeSlots - K) / 2 + 1;   // lanes that own a valid a/b slot
+    // Staging lines are 64 entries: a lane reads up to M entries past its own, and a read past the end of a line lands
+    // in the next line (or the pad).  Only lanes >= NL read there, and their sums feed no stored output.
+    static constexpr int SW = 64;
+    static constexpr int s1_doubles = 6 * SW;             // P, v0 of {sum p, sum g*p, packed guide sums}
+    static constexpr int s2_doubles = 4 * SW + 8;         // P, v0 of {a, b} + pad
+    // lanes >= NL own no a/b slot: the float64 ring masks them (a dummy entry would cost the fifth wavefront per CU),
+    // the fixed-point ring gives them one shared dummy entry (no exec masking in the row loop)
+    static constexpr int NLp(bool fx) { return fx ? NL + 1 : NL; }
+    static constexpr int ring_bytes(bool fx) { return RC * NLp(fx) * (fx ? 16 : 32); }
+    static constexpr int lds_bytes(bool fx) { return ring_bytes(fx) + (s1_doubles + s2_doubles) * 8; }
+};
+
+__device__ __forceinline__ void pipe_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int pipe_reflect(int p, int len)
+{
+    if (p < 0) p = -p;
+    if (p > len - 1) p = 2 * (len - 1) - p;
+    return min(max(p, 0), len - 1);
+}
+
+__device__ __forceinline__ double pipe_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, y, 1.0), y, y);
+}
+
+// What the loads of one step return, untouched: the phases unpack at the point of use (an unpack right after the load
+// would make the wave wait for it at once -- the loads are issued a step ahead).  PAIR: a lane's two slots are adjacent
+// columns and come as one 8-byte / 2-byte load; otherwise one load per slot.
+struct PipeIn {
+    uint32_t te[2], tl[2];  // float bits
+    uint32_t ge[2], gl[2], go[2];  // PAIR: [0] holds both bytes
+};
+template <bool PAIR>
+__device__ __forceinline__ uint32_t pipe_byte(const uint32_t (&v)[2], int c)
+{
+    if constexpr (PAIR) return c == 0 ? (v[0] & 255u) : (v[0] >> 8);
+    else return v[c];
+}
+
+// one a/b ring entry of a lane (its two slots), in the ring's own number format
+template <bool FX>
+struct RingEntry;
+template <>
+struct RingEntry<false> {
+    double a[2], b[2];
+};
+template <>
+struct RingEntry<true> {
+    int32_t a[2], b[2];
+};
+
+// Raw buffer resource over one image plane (stride 0): loads take a per-lane byte offset (VGPR) plus a wave-uniform row
+// offset (SGPR), so the row loop needs no vector address arithmetic; accesses at or beyond `bytes` are dropped by the
+// hardware's range check, which is also how lanes without a valid output column skip their store (kNoStore).
+constexpr uint32_t kNoStore = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pipe_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t pipe_opaque(uint32_t v)  // keeps a loop-invariant address in its register
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int K, bool FX, typename TOut>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_guided_pipe(const uint8_t *__restrict__ gray, const float *__restrict__ t0,
+                                                       TOut *__restrict__ tout, PipeGeom g, PipeConsts cs)
+{
+    using C = PipeCfg<K>;
+    using Entry = RingEntry<FX>;
+    constexpr int a = C::a, Lb = C::Lb, NV = C::NV, RC = C::RC, NL = C::NL, M = C::M, SW = C::SW;
+    constexpr int NLp = C::NLp(FX), EB = FX ? 16 : 32;
+    constexpr double K2 = (double)(K * K);
+    extern __shared__ double2 lds_raw[];
+    char *lds = reinterpret_cast<char *>(lds_raw);
+
+    const int lane = threadIdx.x;
+    const bool own = lane < NLp;
+    const int H = g.H, W = g.W;
+    const int x_lo = blockIdx.x * NV;
+    const int y_lo = blockIdx.y * g.band, y_hi = min(H, y_lo + g.band);
+    const int r_lo = max(0, y_lo - a), r_hi = min(H - 1, y_hi - 1 + Lb), r_end = y_hi - 1 + a;
+    const size_t img = (size_t)blockIdx.z * H * W;
+    const uint32_t npx = (uint32_t)H * (uint32_t)W;
+    const __amdgpu_buffer_rsrc_t rT = pipe_rsrc(t0 + img, npx * 4u), rG = pipe_rsrc(gray + img, npx),
+                                 rO = pipe_rsrc(tout + img, npx * (uint32_t)sizeof(TOut));
+    const uint32_t pitch_t = (uint32_t)W * 4u, pitch_g = (uint32_t)W, pitch_o = (uint32_t)W * (uint32_t)sizeof(TOut);
+
+    int craw[2], fix_addr[2];
+    bool ook[2], fix_need[2], fix_odd[2];
+    uint32_t ofs_o[2], ofs_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int s = 2 * lane + j;
+        craw[j] = pipe_reflect(x_lo - 2 * a + s, W);
+        const int xo = x_lo + s;
+        ook[j] = s < NV && xo < W;
+        ofs_o[j] = (uint32_t)min(xo, W - 1);
+        ofs_q[j] = ook[j] ? (uint32_t)xo * (uint32_t)sizeof(TOut) : kNoStore;
+        const int c = x_lo - a + s, cr = pipe_reflect(c, W);
+        const int sp = min(max(cr - (x_lo - a), 0), kPipeSlots - 1);
+        fix_need[j] = cr != c;
+        fix_addr[j] = (sp >> 1) << 2;
+        fix_odd[j] = sp & 1;
+    }
+    // strips away from the left/right border (and an even W): a lane's two slots are adjacent, 8/2-byte aligned columns
+    const bool edge = x_lo - 2 * a < 0 || x_lo - 2 * a + kPipeSlots > W || (W & 1);  // wave-uniform
+    const uint32_t ofs_t[2] = {(uint32_t)craw[0] * 4u, (uint32_t)craw[1] * 4u};
+    const uint32_t ofs_g[2] = {(uint32_t)craw[0], (uint32_t)craw[1]};
+
+    // loop-invariant LDS addresses of this lane
+    const uint32_t a_s1 = pipe_opaque((uint32_t)C::ring_bytes(FX) + (uint32_t)lane * 8u);
+    const double *s1 = reinterpret_cast<const double *>(lds + a_s1);      // staging of V1: [P_p | p0 | P_gp | gp0 | P_i | i0]
+    const double *s2 = s1 + C::s1_doubles;                                // staging of V2: [P_a | a0 | P_b | b0]
+    const uint32_t a_ring = pipe_opaque((uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
+
+    // rows of step i: entering raw row i+Lb and leaving raw row i-1-a for A(i), guide of output row i-2-a for C(i-2)
+    auto load_rows = [&](auto pair_tag, uint32_t oe_t, uint32_t ol_t, uint32_t oe_g, uint32_t ol_g, uint32_t oo_g, PipeIn &in) {
+        if constexpr (decltype(pair_tag)::value) {
+            const u32x2 te = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], oe_t, 0);
+            const u32x2 tl = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], ol_t, 0);
+            in.ge[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], oe_g, 0);
+            in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
+            in.go[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_o[0], oo_g, 0);
+            in.te[0] = te.x; in.te[1] = te.y;
+            in.tl[0] = tl.x; in.tl[1] = tl.y;
+            in.ge[1] = in.gl[1] = in.go[1] = 0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                in.te[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], oe_t, 0);
+                in.tl[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], ol_t, 0);
+                in.ge[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], oe_g, 0);
+                in.gl[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], ol_g, 0);
+                in.go[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_o[j], oo_g, 0);
+            }
+        }
+    };
+    auto load_step = [&](int i, PipeIn &in) {  // any step: reflected rows
+        const uint32_t re = (uint32_t)pipe_reflect(i + Lb, H), rl = (uint32_t)pipe_reflect(i - 1 - a, H),
+                       ro = (uint32_t)min(max(i - 2 - a, 0), H - 1);
+        load_rows(std::false_type{}, re * pitch_t, rl * pitch_t, re * pitch_g, rl * pitch_g, ro * pitch_g, in);
+    };
+
+    // ---- prologue: vertical sums of the band's first a/b row by direct summation
+    double V1p[2] = {0.0, 0.0}, V1gp[2] = {0.0, 0.0};  // vertical sums of p and g*p (g = guide byte)
+    uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};          // vertical sums of g and g*g: exact integers
+    double V2a[2] = {0.0, 0.0}, V2b[2] = {0.0, 0.0};   // vertical sums of the ring's a and b (ring units)
+    for (int j = 0; j < K; ++j) {
+        const uint32_t row = (uint32_t)pipe_reflect(r_lo - a + j, H);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t gq = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[c], row * pitch_g, 0);
+            const double p = (double)__uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0));
+            Sg[c] += gq;
+            Sgg[c] += gq * gq;
+            V1p[c] += p;
+            V1gp[c] += (double)gq * p;
+        }
+    }
+
+    int wslot = r_lo % RC;                        // ring slot of the a/b row phase B works on
+    int pslot = wslot == 0 ? RC - 1 : wslot - 1;  // ring slot of the row before it
+
+    // lanes >= NLp own no a/b slot: F64 masks them, FX32 points them at a shared dummy entry (NLp = NL + 1, no masking)
+    auto ring_load = [&](int slot) {
+        Entry e;
+        const char *p = lds + (a_ring + (uint32_t)(slot * NLp * EB));
+        if constexpr (FX) {
+            const int4 v = *reinterpret_cast<const int4 *>(p);
+            e.a[0] = v.x; e.b[0] = v.y; e.a[1] = v.z; e.b[1] = v.w;
+        } else {
+            double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+            if (own) {
+                v0 = reinterpret_cast<const double2 *>(p)[0];
+                v1 = reinterpret_cast<const double2 *>(p)[1];
+            }
+            e.a[0] = v0.x; e.b[0] = v0.y; e.a[1] = v1.x; e.b[1] = v1.y;
+        }
+        return e;
+    };
+    auto ring_store = [&](int slot, const Entry &e) {
+        char *p = lds + (a_ring + (uint32_t)(slot * NLp * EB));
+        if constexpr (FX) {
+            *reinterpret_cast<int4 *>(p) = make_int4(e.a[0], e.b[0], e.a[1], e.b[1]);
+        } else {
+            if (own) {
+                reinterpret_cast<double2 *>(p)[0] = make_double2(e.a[0], e.b[0]);
+                reinterpret_cast<double2 *>(p)[1] = make_double2(e.a[1], e.b[1]);
+            }
+        }
+    };
+    auto v2_add = [&](const Entry &e) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            V2a[c] += (double)e.a[c];
+            V2b[c] += (double)e.b[c];
+        }
+    };
+    auto v2_slide = [&](const Entry &e, const Entry &l) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if constexpr (FX) {  // |fixed| < 2^30: the difference fits
+                V2a[c] += (double)(e.a[c] - l.a[c]);
+                V2b[c] += (double)(e.b[c] - l.b[c]);
+            } else {
+                V2a[c] += e.a[c] - l.a[c];
+                V2b[c] += e.b[c] - l.b[c];
+            }
+        }
+    };
+
+    auto store_row = [&](auto pair_tag, uint32_t orow, const double *q) {  // orow: byte offset of the output row
+        if constexpr (std::is_same<TOut, double>::value) {
+            // (always two 8-byte stores: a 16-byte buffer store with an SGPR row offset was seen to pick up the NEXT
+            // instruction's write to its data registers on gfx950 -- the compiler only guards that hazard for stores
+            // without a register soffset)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q[c]), rO, ofs_q[c], orow, 0);
+        } else {
+            if constexpr (decltype(pair_tag)::value) {
+                const float2 v = make_float2((float)q[0], (float)q[1]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v),
+                                                      rO, ofs_q[0], orow, 0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)q[c]), rO, ofs_q[c], orow, 0);
+            }
+        }
+    };
+
+    // window sums of one float64 plane from its staging lines: o0 = slots 2l .. 2l+K-1, o1 = slots 2l+1 .. 2l+K
+    auto window = [&](const double *ps, double P, double v1, double &o0, double &o1) {
+        double mid0 = ps[1], mid1 = ps[2];
+#pragma unroll
+        for (int d = 3; d < M; d += 2) mid0 += ps[d];
+#pragma unroll
+        for (int d = 4; d < M; d += 2) mid1 += ps[d];
+        const double mid = mid0 + mid1, f0 = ps[SW + M];
+        if constexpr (K & 1) {
+            o0 = (P + mid) + f0;
+            o1 = (v1 + mid) + ps[M];
+        } else {
+            o0 = P + mid;
+            o1 = (v1 + mid) + f0;
+        }
+    };
+
+    // One step.  FULL: all three phases in their steady state (no band start/end, no reflected rows): straight-line code.
+    // orow_c: byte offset of output row i-2-a (FULL steps; the others compute it)
+    auto step = [&](auto full_tag, auto edge_tag, int i, const PipeIn &in, uint32_t orow_c) {
+        constexpr bool FULL = decltype(full_tag)::value, EDGE = decltype(edge_tag)::value, PAIR = FULL && !EDGE;
+        const int rB = i - 1, rC = i - 2;
+        const bool doB = FULL || (rB >= r_lo && rB <= r_end), doC = FULL || (rC >= r_lo && rC <= r_end);
+        const bool doB1 = doB && (FULL || rB <= r_hi);          // a/b row rB exists in this band
+        const bool doB2 = doB && (FULL || rB - a >= y_lo);      // output row rB - a belongs to this band
+        const bool doC2 = doC && (FULL || rC - a >= y_lo);
+        const bool doA1 = FULL || i <= r_hi;
+        double *w1 = const_cast<double *>(s1), *w2 = const_cast<double *>(s2);
+        const uint2 *s1i = reinterpret_cast<const uint2 *>(s1 + 4 * SW);
+
+        // ================= read phase
+        // C(i-2): window sums of the staged V2
+        double oa[2] = {0.0, 0.0}, ob[2] = {0.0, 0.0};
+        if (doC2) {
+            window(s2, V2a[0] + V2a[1], V2a[1], oa[0], oa[1]);
+            window(s2 + 2 * SW, V2b[0] + V2b[1], V2b[1], ob[0], ob[1]);
+        }
+        // B(i-1): window sums of the staged V1, the leaving (and, for even K, entering) ring rows
+        double oP[2] = {0.0, 0.0}, oGP[2] = {0.0, 0.0};
+        uint32_t oG[2] = {0, 0}, oGG[2] = {0, 0};
+        Entry lv{}, ev{};
+        if (doB1) {
+            window(s1, V1p[0] + V1p[1], V1p[1], oP[0], oP[1]);
+            window(s1 + 2 * SW, V1gp[0] + V1gp[1], V1gp[1], oGP[0], oGP[1]);
+            const uint2 *ps = s1i;
+            uint2 m0 = ps[1], m1 = ps[2];
+#pragma unroll
+            for (int d = 3; d < M; d += 2) { m0.x += ps[d].x; m0.y += ps[d].y; }
+#pragma unroll
+            for (int d = 4; d < M; d += 2) { m1.x += ps[d].x; m1.y += ps[d].y; }
+            const uint32_t midg = m0.x + m1.x, midgg = m0.y + m1.y;
+            const uint2 f0 = ps[SW + M];
+            if constexpr (K & 1) {
+                const uint2 pm = ps[M];
+                oG[0] = Sg[0] + Sg[1] + midg + f0.x;   oGG[0] = Sgg[0] + Sgg[1] + midgg + f0.y;
+                oG[1] = Sg[1] + midg + pm.x;           oGG[1] = Sgg[1] + midgg + pm.y;
+            } else {
+                oG[0] = Sg[0] + Sg[1] + midg;          oGG[0] = Sgg[0] + Sgg[1] + midgg;
+                oG[1] = Sg[1] + midg + f0.x;           oGG[1] = Sgg[1] + midgg + f0.y;
+            }
+        }
+        if (FULL) {
+            lv = ring_load(wslot);                          // row rB - RC, about to be overwritten by row rB
+            if constexpr (!(K & 1)) ev = ring_load(pslot);  // even K: entering row rB - 1
+        }
+
+        // ================= compute
+        // C: q = mean_a * I + mean_b, clip (six_stadigy.py:45,180)
+        if (doC2) {
+            double q[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double gd = (double)pipe_byte<PAIR>(in.go, c);
+                q[c] = fmin(fmax(fma(oa[c] * cs.kaI, gd, fma(ob[c], cs.kb, cs.b0)), 0.1), 1.0);
+            }
+#ifdef PIPE_KO_STORE
+            if (q[0] + q[1] == 12345.0)
+#endif
+            if constexpr (FULL && !EDGE) store_row(std::true_type{}, orow_c, q);
+            else store_row(std::false_type{}, FULL ? orow_c : (uint32_t)(rC - a) * pitch_o, q);
+        }
+        // B: a = cov / (var + eps), b = mean_p - a * mean_I (six_stadigy.py:39-40) in the ring's format
+        Entry nv{};
+        if (doB1) {
+            double av[2], bt[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t nvar = oGG[c] * (uint32_t)(K * K) - oG[c] * oG[c];  // (255 K^2)^2 var: exact (mod 2^32, < 2^32)
+                const double D = fma((double)nvar, 1.0 / 255.0, cs.Ek);            // 255 K^4 (var + eps)
+                const double gd = (double)oG[c];
+                const double ncov = fma(K2, oGP[c], -(gd * oP[c]));                // 255 K^4 cov
+                av[c] = ncov * pipe_rcp(D);
+                bt[c] = fma(av[c] * (-1.0 / 255.0), gd, oP[c]);                    // K^2 b
+            }
+            if constexpr (FX) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    nv.a[c] = __double2loint(fma(av[c], cs.fxa, kMagic));
+                    nv.b[c] = __double2loint(fma(bt[c], cs.fxb, cs.magic_b));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    nv.a[c] = av[c];
+                    nv.b[c] = bt[c] * (1.0 / K2);
+                }
+            }
+            if (EDGE) {  // a/b of virtual columns = a/b of the mirrored real column (cv2.boxFilter pads its source)
+                Entry fx = nv;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (FX) {
+                        const int a0 = __builtin_amdgcn_ds_bpermute(fix_addr[c], nv.a[0]), a1 = __builtin_amdgcn_ds_bpermute(fix_addr[c], nv.a[1]);
+                        const int b0 = __builtin_amdgcn_ds_bpermute(fix_addr[c], nv.b[0]), b1 = __builtin_amdgcn_ds_bpermute(fix_addr[c], nv.b[1]);
+                        if (fix_need[c]) {
+                            fx.a[c] = fix_odd[c] ? a1 : a0;
+                            fx.b[c] = fix_odd[c] ? b1 : b0;
+                        }
+                    } else {
+                        auto bp = [&](double v) {
+                            const int lo = __builtin_amdgcn_ds_bpermute(fix_addr[c], __double2loint(v));
+                            const int hi = __builtin_amdgcn_ds_bpermute(fix_addr[c], __double2hiint(v));
+                            return __hiloint2double(hi, lo);
+                        };
+                        const double a0 = bp(nv.a[0]), a1 = bp(nv.a[1]), b0 = bp(nv.b[0]), b1 = bp(nv.b[1]);
+                        if (fix_need[c]) {
+                            fx.a[c] = fix_odd[c] ? a1 : a0;
+                            fx.b[c] = fix_odd[c] ? b1 : b0;
+                        }
+                    }
+                }
+                nv = fx;
+            }
+        }
+        bool ring_written = false;
+        if (doB2) {
+            if (FULL) {
+                if constexpr (K & 1) v2_slide(nv, lv);   // odd K: the entering row is the row just computed
+                else v2_slide(ev, lv);
+            } else {
+                // band start / end and reflected rows: the ring is addressed by reflect101(row) % RC.  The leaving row
+                // shares its slot with the new row, so it is read first; then the new row goes in, then the rest.
+                const int y2 = rB - a;
+                const bool slide = y2 != y_lo;
+                Entry l{};
+                if (slide) l = ring_load(pipe_reflect(y2 - 1 - a, H) % RC);
+                if (doB1) {
+                    pipe_sync();
+                    ring_store(wslot, nv);
+                    pipe_sync();
+                    ring_written = true;
+                }
+                if (!slide) {
+                    V2a[0] = V2a[1] = V2b[0] = V2b[1] = 0.0;
+                    for (int j = 0; j < K; ++j) v2_add(ring_load(pipe_reflect(y_lo - a + j, H) % RC));
+                } else {
+                    v2_slide(ring_load(pipe_reflect(y2 + Lb, H) % RC), l);
+                }
+            }
+        }
+        // A: V1 += raw(entering) - raw(leaving)
+        if (doA1 && (FULL || i != r_lo)) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double pe = (double)__uint_as_float(in.te[c]), pl = (double)__uint_as_float(in.tl[c]);
+                const uint32_t ge = pipe_byte<PAIR>(in.ge, c), gl = pipe_byte<PAIR>(in.gl, c);
+                Sg[c] += ge - gl;
+                Sgg[c] += ge * ge - gl * gl;
+                V1p[c] += pe - pl;
+                V1gp[c] += (double)ge * pe - (double)gl * pl;
+            }
+        }
+
+        // ================= write phase
+        pipe_sync();
+        if (doA1) {
+            w1[0] = V1p[0] + V1p[1];
+            w1[SW] = V1p[0];
+            w1[2 * SW] = V1gp[0] + V1gp[1];
+            w1[3 * SW] = V1gp[0];
+            uint2 *wi = reinterpret_cast<uint2 *>(w1 + 4 * SW);
+            wi[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
+            wi[SW] = make_uint2(Sg[0], Sgg[0]);
+        }
+        if (doB2) {
+            w2[0] = V2a[0] + V2a[1];
+            w2[SW] = V2a[0];
+            w2[2 * SW] = V2b[0] + V2b[1];
+            w2[3 * SW] = V2b[0];
+        }
+        if (doB1) {
+            if (!ring_written) ring_store(wslot, nv);
+            pslot = wslot;
+            wslot = wslot + 1 == RC ? 0 : wslot + 1;
+        }
+        pipe_sync();
+    };
+
+    using T = std::true_type;
+    using F = std::false_type;
+    // FULL steps i in [f_lo, f_hi]: phases C(i-2), B(i-1), A(i) all steady, and neither this step's stores nor the next
+    // step's loads touch a reflected row, so every row offset advances by one pitch per step
+    const int f_lo = max(r_lo + 2 + RC, a + 2), f_hi = min(r_hi, H - 2 - Lb);
+    PipeIn nxt;
+    load_step(r_lo, nxt);
+    int i = r_lo;
+    while (i <= r_end + 2) {
+        if (i >= f_lo && i <= f_hi) {
+            // row offsets of the loads for step i+1 and of the store of step i
+            uint32_t oe_t = (uint32_t)(i + 1 + Lb) * pitch_t, ol_t = (uint32_t)(i - a) * pitch_t;
+            uint32_t oe_g = (uint32_t)(i + 1 + Lb) * pitch_g, ol_g = (uint32_t)(i - a) * pitch_g, oo_g = (uint32_t)(i - 1 - a) * pitch_g;
+            uint32_t orow = (uint32_t)(i - 2 - a) * pitch_o;
+            // two steps per trip, the row buffers alternating roles (no register copies: a copy would wait for its load)
+            auto advance = [&]() {
+                oe_t += pitch_t; ol_t += pitch_t; oe_g += pitch_g; ol_g += pitch_g; oo_g += pitch_g; orow += pitch_o;
+            };
+            if (!edge) {
+                PipeIn alt;
+                // the steps outside this loop keep one byte per slot: repack on the way in, unpack on the way out
+                nxt.ge[0] |= nxt.ge[1] << 8; nxt.gl[0] |= nxt.gl[1] << 8; nxt.go[0] |= nxt.go[1] << 8;
+                for (; i + 1 <= f_hi; i += 2) {
+#ifndef PIPE_KO_LOADS
+                    load_rows(T{}, oe_t, ol_t, oe_g, ol_g, oo_g, alt);
+#endif
+                    step(T{}, F{}, i, nxt, orow);
+                    advance();
+#ifdef PIPE_SCHED_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef PIPE_KO_LOADS
+                    load_rows(T{}, oe_t, ol_t, oe_g, ol_g, oo_g, nxt);
+#endif
+                    step(T{}, F{}, i + 1, alt, orow);
+                    advance();
+#ifdef PIPE_SCHED_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+                if (i <= f_hi) {
+                    load_rows(T{}, oe_t, ol_t, oe_g, ol_g, oo_g, alt);
+                    step(T{}, F{}, i, nxt, orow);
+                    nxt = alt;
+                    ++i;
+                }
+                nxt.ge[1] = nxt.ge[0] >> 8; nxt.gl[1] = nxt.gl[0] >> 8; nxt.go[1] = nxt.go[0] >> 8;
+                nxt.ge[0] &= 255u; nxt.gl[0] &= 255u; nxt.go[0] &= 255u;
+            } else {
+                for (; i <= f_hi; ++i) {
+                    const PipeIn cur = nxt;
+                    load_rows(F{}, oe_t, ol_t, oe_g, ol_g, oo_g, nxt);
+                    step(T{}, T{}, i, cur, orow);
+                    advance();
+                }
+            }
+        } else {
+            const PipeIn cur = nxt;
+            load_step(i + 1, nxt);
+            step(F{}, T{}, i, cur, 0u);
+            ++i;
+        }
+    }
+}
+
+template <int K, bool FX, typename TOut>
+int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, hipStream_t st)
+{
+    using C = PipeCfg<K>;
+    constexpr int lds = C::lds_bytes(FX);
+    const int nstrips = cdiv(s.W, C::NV);
+    const int resident = 256 * std::max(1, std::min(8, (160 * 1024) / lds));
+    int nbands = 1;
+    static const char *env = getenv("UWIE_GF_BANDS");
+    if (env) nbands = atoi(env);
+    else {
+        const long strips = (long)nstrips * s.B;
+        if (strips < 12L * resident) nbands = (int)cdiv((size_t)(12L * resident), (size_t)strips);
+        const int cap = std::max(1, s.H / (16 * (K - 1)));
+        nbands = std::min(nbands, std::max(cap, (int)cdiv((size_t)(3L * resident), (size_t)strips)));
+    }
+    nbands = std::max(1, std::min(nbands, s.H / std::max(64, 4 * K)));
+    PipeGeom g;
+    g.H = s.H; g.W = s.W;
+    g.band = cdiv(s.H, nbands);
+    const int gy = cdiv(s.H, g.band);
+    {
+        UWIE_PROF("k_guided_pipe", st);
+        hipLaunchKernelGGL((k_guided_pipe<K, FX, TOut>), dim3(nstrips, gy, s.B), dim3(64), (size_t)lds, st, d_gray, d_t0, d_t, g, cs);
+    }
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+}  // namespace
+
+// ring: 0 = float64, 1 = fixed-point int32 (requires 0.1 <= t0 <= 1: the caller's pre-clip, six_stadigy.py:174)
+int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
+                       int *handled, hipStream_t st)
+{
+    *handled = 0;
+    if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || !(eps > 0.0)) return UWIE_OK;
+    if (k != 10 && k != 15 && k != 20) return UWIE_OK;
+    const double K2 = (double)k * k, scale = 1.0 / K2;
+    PipeConsts cs{};
+    cs.Ek = 255.0 * K2 * K2 * eps;
+    if (ring == 1) {
+        // |cov| <= sigma_p * sigma_I, sigma_p <= 0.45, sigma_I <= 0.5:  |a| <= 0.45 s / (s^2 + eps), s = sigma_I
+        const double se = std::sqrt(eps);
+        const double amax = (se <= 0.5 ? 0.45 / (2.0 * se) : 0.225 / (0.25 + eps)) * 1.02;
+        const double hb = (0.45 + amax) * 1.02;   // |b - 0.55|
+        const int Sa = (int)std::floor(std::log2(1073741824.0 / amax)), Sb = (int)std::floor(std::log2(1073741824.0 / hb));
+        if (Sa < 28 || Sb < 28) ring = 0;  // wide a/b range (tiny eps): keep float64
+        else {
+            const double fa = std::ldexp(1.0, Sa), fb = std::ldexp(1.0, Sb);
+            const double b0i = std::nearbyint(0.55 * fb);
+            cs.fxa = fa;
+            cs.fxb = scale * fb;
+            cs.magic_b = kMagic - b0i;
+            cs.kaI = scale / 255.0 / fa;
+            cs.kb = scale / fb;
+            cs.b0 = b0i / fb;
+        }
+    }
+    if (ring == 0) {
+        cs.kaI = scale / 255.0;
+        cs.kb = scale;
+        cs.b0 = 0.0;
+    }
+    int rc;
+#define UWIE_PIPE_CASE(KK)                                                                                   \
+    case KK:                                                                                                 \
+        rc = ring == 1 ? launch_pipe<KK, true, double>(d_gray, d_t0, s, cs, d_t, st)                         \
+                       : launch_pipe<KK, false, double>(d_gray, d_t0, s, cs, d_t, st);                       \
+        break;
+    switch (k) {
+        UWIE_PIPE_CASE(10)
+        UWIE_PIPE_CASE(15)
+        UWIE_PIPE_CASE(20)
+    default: return UWIE_OK;
+    }
+#undef UWIE_PIPE_CASE
+    if (rc == UWIE_OK) *handled = 1;
+    return rc;
+}
+
+}  // namespace uwie
