@@ -34,10 +34,17 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace uwie {
 
 namespace {
+
+#define UWIE_TRY_RC(call)               \
+    do {                                \
+        const int _rc = (call);         \
+        if (_rc != UWIE_OK) return _rc; \
+    } while (0)
 
 constexpr int kPipeSlots = 128;
 constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: fma(x, s, kMagic) has round-to-nearest(x*s) in its low word
@@ -47,6 +54,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct PipeGeom {
     int H, W, band;
+    // Border launch around an interior block that k_guided_split covers (iy1 > iy0): blockIdx.y 0 = rows [0, iy0),
+    // 1 = rows [iy1, H), 2.. = the interior's own bands (iband rows each) for the strips outside [is0, is1) only.
+    int iy0, iy1, iband, is0, is1;
 };
 
 struct PipeConsts {
@@ -60,7 +70,7 @@ struct PipeConsts {
 
 template <int K>
 struct PipeCfg {
-    static constexpr int a = K / 2, Lb = K - 1 - a, M = K / 2;
+    static constexpr int K_ = K, a = K / 2, Lb = K - 1 - a, M = K / 2;
     static constexpr int NV = kPipeSlots - 2 * (K - 1);   // output columns per strip
     static constexpr int RC = 2 * a + 1;                  // ring rows
     static constexpr int NL = (kPipeSlots - K) / 2 + 1;   // lanes that own a valid a/b slot
@@ -153,7 +163,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool own = lane < NLp;
     const int H = g.H, W = g.W;
     const int x_lo = blockIdx.x * NV;
-    const int y_lo = blockIdx.y * g.band, y_hi = min(H, y_lo + g.band);
+    int y_lo = blockIdx.y * g.band, y_hi = min(H, y_lo + g.band);
+    if (g.iy1 > g.iy0) {  // border launch (wave-uniform)
+        if (blockIdx.y == 0) { y_lo = 0; y_hi = g.iy0; }
+        else if (blockIdx.y == 1) { y_lo = g.iy1; y_hi = H; }
+        else {
+            if ((int)blockIdx.x >= g.is0 && (int)blockIdx.x < g.is1) return;
+            y_lo = g.iy0 + ((int)blockIdx.y - 2) * g.iband;
+            y_hi = y_lo + g.iband;
+        }
+        if (y_lo >= y_hi) return;
+    }
     const int r_lo = max(0, y_lo - a), r_hi = min(H - 1, y_hi - 1 + Lb), r_end = y_hi - 1 + a;
     const size_t img = (size_t)blockIdx.z * H * W;
     const uint32_t npx = (uint32_t)H * (uint32_t)W;
@@ -569,8 +589,336 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
+
+// ---------------------------------------------------------------- split ring: a in LDS, b in registers (float64, k = 15)
+// The b half of the ring: N rows x 2 slots of float64 that must live in registers: a recursive struct of scalars with
+// compile-time access (an array would have to be proven constant-indexed after unrolling and was seen to stay in
+// scratch memory).
+template <int N>
+struct RegRing {
+    double x0, x1;
+    RegRing<N - 1> rest;
+    template <int S>
+    __device__ __forceinline__ void swap_at(double &b0, double &b1)  // returns the old entry, stores the new one
+    {
+        if constexpr (S == 0) {
+            const double o0 = x0, o1 = x1;
+            x0 = b0; x1 = b1;
+            b0 = o0; b1 = o1;
+        } else rest.template swap_at<S - 1>(b0, b1);
+    }
+    __device__ __forceinline__ void clear() { x0 = x1 = 0.0; rest.clear(); }
+};
+template <>
+struct RegRing<0> {
+    template <int S> __device__ __forceinline__ void swap_at(double &, double &) {}
+    __device__ __forceinline__ void clear() {}
+};
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+struct SplitGeom {
+    int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
+};
+
+// Interior blocks only: every raw row/column the band touches exists (no reflection), W even, band % RC == 0.  Then a
+// band is: V1 of its first a/b row by direct summation, one WARM ring period (phases A and B only: the ring and V2
+// fill up from zero, which IS the direct sum of the first window because the leaving rows are the zeros the ring was
+// cleared to), and band/RC periods of identical steps.  Every step of a period has its ring slot as a compile-time
+// constant: b lives in registers, the LDS address of a is an immediate, and there is no slot arithmetic at all.
+template <int K, bool EDGE, typename TOut>
+__device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, const float *__restrict__ t0, TOut *__restrict__ tout,
+                                           const SplitGeom &g, const PipeConsts &cs, char *lds)
+{
+    using C = PipeCfg<K>;
+    static_assert(K & 1, "odd window widths only (the entering row is the row just computed)");
+    constexpr int a = C::a, Lb = C::Lb, NV = C::NV, RC = C::RC, NL = C::NL, M = C::M, SW = C::SW;
+    static_assert(RC % 3 == 0, "the ring period must be a multiple of the three row buffers");
+    constexpr int NLp = NL + 1, EB = 16;
+    constexpr int ring_bytes = RC * NLp * EB;
+    constexpr double K2 = (double)(K * K);
+    const int lane = threadIdx.x;
+    const int H = g.H, W = g.W;
+    const int x_lo = (int)blockIdx.x * NV;
+    const int y_lo = g.y0 + (int)blockIdx.y * g.band;
+    const int r_lo = y_lo - a;
+    const size_t img = (size_t)blockIdx.z * H * W;
+    const uint32_t npx = (uint32_t)H * (uint32_t)W;
+    const __amdgpu_buffer_rsrc_t rT = pipe_rsrc(t0 + img, npx * 4u), rG = pipe_rsrc(gray + img, npx),
+                                 rO = pipe_rsrc(tout + img, npx * (uint32_t)sizeof(TOut));
+    const uint32_t pitch_t = (uint32_t)W * 4u, pitch_g = (uint32_t)W, pitch_o = (uint32_t)W * (uint32_t)sizeof(TOut);
+
+    // Interior strips (!EDGE): a lane's two slots are adjacent raw columns inside the image: one 8-byte / 2-byte load for
+    // both.  EDGE strips (their raw columns run over the left/right image border): reflected columns, one load per slot,
+    // and the a/b of virtual columns replaced by those of the mirrored real column (cv2.boxFilter pads its source).
+    const int xo0 = x_lo + 2 * lane;
+    int craw[2], fix_addr[2];
+    bool fix_need[2], fix_odd[2];
+    uint32_t ofs_t[2], ofs_g[2], ofs_o[2], ofs_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sl = 2 * lane + j;
+        craw[j] = EDGE ? pipe_reflect(x_lo - 2 * a + sl, W) : x_lo - 2 * a + sl;
+        ofs_t[j] = (uint32_t)craw[j] * 4u;
+        ofs_g[j] = (uint32_t)craw[j];
+        ofs_o[j] = EDGE ? (uint32_t)min(xo0 + j, W - 1) : (uint32_t)min(xo0, W - 2);
+        ofs_q[j] = sl < NV && xo0 + j < W ? (uint32_t)(xo0 + j) * (uint32_t)sizeof(TOut) : kNoStore;
+        const int c = x_lo - a + sl, cr = pipe_reflect(c, W);
+        const int sp = min(max(cr - (x_lo - a), 0), kPipeSlots - 1);
+        fix_need[j] = EDGE && cr != c;
+        fix_addr[j] = (sp >> 1) << 2;
+        fix_odd[j] = sp & 1;
+    }
+
+    const uint32_t a_s1 = pipe_opaque((uint32_t)ring_bytes + (uint32_t)lane * 8u);
+    const double *s1 = reinterpret_cast<const double *>(lds + a_s1);
+    const double *s2 = s1 + C::s1_doubles;
+    const uint32_t a_ring = pipe_opaque((uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
+
+    // what the loads return, untouched (unpacked at the point of use: an early unpack would wait for the load at once)
+    struct In {
+        uint32_t te[2], tl[2];
+        uint32_t ge[2], gl[2], go[2];  // !EDGE: [0] holds both bytes
+    };
+    auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
+    auto load_rows = [&](uint32_t oe_t, uint32_t ol_t, uint32_t oe_g, uint32_t ol_g, uint32_t oo_g, In &in) {
+        if constexpr (!EDGE) {
+            const u32x2 te = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], oe_t, 0);
+            const u32x2 tl = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], ol_t, 0);
+            in.ge[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], oe_g, 0);
+            in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
+            in.go[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_o[0], oo_g, 0);
+            in.te[0] = te.x; in.te[1] = te.y;
+            in.tl[0] = tl.x; in.tl[1] = tl.y;
+            in.ge[1] = in.gl[1] = in.go[1] = 0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                in.te[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], oe_t, 0);
+                in.tl[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], ol_t, 0);
+                in.ge[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], oe_g, 0);
+                in.gl[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], ol_g, 0);
+                in.go[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_o[j], oo_g, 0);
+            }
+        }
+    };
+
+    // ---- prologue: vertical sums of a/b row r_lo by direct summation; ring and V2 start from zero
+    double V1p[2] = {0.0, 0.0}, V1gp[2] = {0.0, 0.0};
+    uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};
+    double V2a[2] = {0.0, 0.0}, V2b[2] = {0.0, 0.0};
+    for (int j = 0; j < K; ++j) {
+        const uint32_t row = (uint32_t)(r_lo - a + j);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t gq = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[c], row * pitch_g, 0);
+            const double p = (double)__uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0));
+            Sg[c] += gq;
+            Sgg[c] += gq * gq;
+            V1p[c] += p;
+            V1gp[c] += (double)gq * p;
+        }
+    }
+    RegRing<RC> rb;
+    rb.clear();
+#pragma unroll
+    for (int s = 0; s < RC; ++s) *reinterpret_cast<double2 *>(lds + a_ring + (uint32_t)(s * NLp * EB)) = make_double2(0.0, 0.0);
+
+    auto window = [&](const double *ps, double P, double v1, double &o0, double &o1) {
+        double mid0 = ps[1], mid1 = ps[2];
+#pragma unroll
+        for (int d = 3; d < M; d += 2) mid0 += ps[d];
+#pragma unroll
+        for (int d = 4; d < M; d += 2) mid1 += ps[d];
+        const double mid = mid0 + mid1, f0 = ps[SW + M];
+        o0 = (P + mid) + f0;
+        o1 = (v1 + mid) + ps[M];
+    };
+    auto stage_v1 = [&]() {
+        double *w1 = const_cast<double *>(s1);
+        w1[0] = V1p[0] + V1p[1];
+        w1[SW] = V1p[0];
+        w1[2 * SW] = V1gp[0] + V1gp[1];
+        w1[3 * SW] = V1gp[0];
+        uint2 *wi = reinterpret_cast<uint2 *>(w1 + 4 * SW);
+        wi[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
+        wi[SW] = make_uint2(Sg[0], Sgg[0]);
+    };
+
+    // One step i: C(i-2) [not in the warm period], B(i-1) on ring slot S, A(i).
+    auto step = [&](auto warm_tag, auto slot_tag, const In &in, uint32_t orow) {
+        constexpr bool WARM = decltype(warm_tag)::value;
+        constexpr int S = decltype(slot_tag)::value;
+        double *w2 = const_cast<double *>(s2);
+        const uint2 *s1i = reinterpret_cast<const uint2 *>(s1 + 4 * SW);
+        char *ring_p = lds + a_ring + (uint32_t)(S * NLp * EB);
+
+        // ================= read phase
+        double oa[2] = {0.0, 0.0}, ob[2] = {0.0, 0.0};
+        if constexpr (!WARM) {
+            window(s2, V2a[0] + V2a[1], V2a[1], oa[0], oa[1]);
+            window(s2 + 2 * SW, V2b[0] + V2b[1], V2b[1], ob[0], ob[1]);
+        }
+        double oP[2], oGP[2];
+        uint32_t oG[2], oGG[2];
+        window(s1, V1p[0] + V1p[1], V1p[1], oP[0], oP[1]);
+        window(s1 + 2 * SW, V1gp[0] + V1gp[1], V1gp[1], oGP[0], oGP[1]);
+        {
+            const uint2 *ps = s1i;
+            uint2 m0 = ps[1], m1 = ps[2];
+#pragma unroll
+            for (int d = 3; d < M; d += 2) { m0.x += ps[d].x; m0.y += ps[d].y; }
+#pragma unroll
+            for (int d = 4; d < M; d += 2) { m1.x += ps[d].x; m1.y += ps[d].y; }
+            const uint32_t midg = m0.x + m1.x, midgg = m0.y + m1.y;
+            const uint2 f0 = ps[SW + M], pm = ps[M];
+            oG[0] = Sg[0] + Sg[1] + midg + f0.x;   oGG[0] = Sgg[0] + Sgg[1] + midgg + f0.y;
+            oG[1] = Sg[1] + midg + pm.x;           oGG[1] = Sgg[1] + midgg + pm.y;
+        }
+        const double2 la = *reinterpret_cast<const double2 *>(ring_p);  // a of the leaving row (same slot)
+
+        // ================= compute
+        if constexpr (!WARM) {  // C: q = mean_a * I + mean_b, clip (six_stadigy.py:45,180)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double gd = (double)byte_of(in.go, c);
+                const double q = fmin(fmax(fma(oa[c] * cs.kaI, gd, fma(ob[c], cs.kb, cs.b0)), 0.1), 1.0);
+                if constexpr (std::is_same<TOut, double>::value)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q), rO, ofs_q[c], orow, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)q), rO, ofs_q[c], orow, 0);
+            }
+        }
+        // B: a = cov / (var + eps), b = mean_p - a * mean_I (six_stadigy.py:39-40)
+        double av[2], bv[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t nvar = oGG[c] * (uint32_t)(K * K) - oG[c] * oG[c];  // (255 K^2)^2 var: exact
+            const double D = fma((double)nvar, 1.0 / 255.0, cs.Ek);            // 255 K^4 (var + eps)
+            const double gd = (double)oG[c];
+            const double ncov = fma(K2, oGP[c], -(gd * oP[c]));                // 255 K^4 cov
+            av[c] = ncov * pipe_rcp(D);
+            bv[c] = fma(av[c] * (-1.0 / 255.0), gd, oP[c]) * (1.0 / K2);
+        }
+        if constexpr (EDGE) {
+            double fa[2] = {av[0], av[1]}, fb[2] = {bv[0], bv[1]};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                auto bp = [&](double v) {
+                    const int lo = __builtin_amdgcn_ds_bpermute(fix_addr[c], __double2loint(v));
+                    const int hi = __builtin_amdgcn_ds_bpermute(fix_addr[c], __double2hiint(v));
+                    return __hiloint2double(hi, lo);
+                };
+                const double a0 = bp(av[0]), a1 = bp(av[1]), b0 = bp(bv[0]), b1 = bp(bv[1]);
+                if (fix_need[c]) {
+                    fa[c] = fix_odd[c] ? a1 : a0;
+                    fb[c] = fix_odd[c] ? b1 : b0;
+                }
+            }
+            av[0] = fa[0]; av[1] = fa[1];
+            bv[0] = fb[0]; bv[1] = fb[1];
+        }
+        double lb0 = bv[0], lb1 = bv[1];
+        rb.template swap_at<S>(lb0, lb1);  // registers: new b in, b of the leaving row out
+        V2a[0] += av[0] - la.x; V2a[1] += av[1] - la.y;
+        V2b[0] += bv[0] - lb0;  V2b[1] += bv[1] - lb1;
+        // A: V1 += raw(entering) - raw(leaving)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double pe = (double)__uint_as_float(in.te[c]), pl = (double)__uint_as_float(in.tl[c]);
+            const uint32_t ge = byte_of(in.ge, c), gl = byte_of(in.gl, c);
+            Sg[c] += ge - gl;
+            Sgg[c] += ge * ge - gl * gl;
+            V1p[c] += pe - pl;
+            V1gp[c] += (double)ge * pe - (double)gl * pl;
+        }
+
+        // ================= write phase
+        pipe_sync();
+        stage_v1();
+        w2[0] = V2a[0] + V2a[1];
+        w2[SW] = V2a[0];
+        w2[2 * SW] = V2b[0] + V2b[1];
+        w2[3 * SW] = V2b[0];
+        *reinterpret_cast<double2 *>(ring_p) = make_double2(av[0], av[1]);
+        pipe_sync();
+    };
+
+    // fill: stage V1(r_lo); loads for steps r_lo+1 and r_lo+2 (step i: rows i+Lb entering, i-1-a leaving, i-2-a guide)
+    pipe_sync();
+    stage_v1();
+    pipe_sync();
+    int i = r_lo + 1;
+    uint32_t oe_t = (uint32_t)(i + Lb) * pitch_t, ol_t = (uint32_t)(i - 1 - a) * pitch_t;
+    uint32_t oe_g = (uint32_t)(i + Lb) * pitch_g, ol_g = (uint32_t)(i - 1 - a) * pitch_g;
+    uint32_t oo_g = (uint32_t)max(i - 2 - a, 0) * pitch_g;  // (unused before the first normal step: i - 2 - a = y_lo there)
+    auto advance_loads = [&]() { oe_t += pitch_t; ol_t += pitch_t; oe_g += pitch_g; ol_g += pitch_g; };
+    In b0, b1, b2;
+    load_rows(oe_t, ol_t, oe_g, ol_g, oo_g, b0);
+    advance_loads();
+    load_rows(oe_t, ol_t, oe_g, ol_g, oo_g, b1);
+    advance_loads();
+    // guide rows of C: step i stores row i-2-a; its byte comes with the loads issued two steps earlier.  The first normal
+    // step is i = r_lo+RC+1 (row y_lo), loaded at warm step n = RC-2.
+    uint32_t orow = (uint32_t)y_lo * pitch_o;
+    auto one = [&](auto warm_tag, auto slot_tag, In &fill, const In &use, uint32_t guide_row_ofs) {
+        load_rows(oe_t, ol_t, oe_g, ol_g, guide_row_ofs, fill);
+        step(warm_tag, slot_tag, use, orow);
+        advance_loads();
+        if constexpr (!decltype(warm_tag)::value) orow += pitch_o;
+        __builtin_amdgcn_sched_barrier(0);  // one step's LDS reads are not stretched over its neighbours (VGPR budget)
+    };
+    auto period = [&](auto warm_tag, uint32_t &gofs) {
+        auto triple = [&](auto base_tag) {
+            constexpr int S0 = decltype(base_tag)::value;
+            one(warm_tag, IC<S0>{}, b2, b0, gofs); gofs += pitch_g;
+            one(warm_tag, IC<S0 + 1>{}, b0, b1, gofs); gofs += pitch_g;
+            one(warm_tag, IC<S0 + 2>{}, b1, b2, gofs); gofs += pitch_g;
+        };
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (triple(IC<3 * Q>{}), ...); }(std::make_integer_sequence<int, RC / 3>{});
+    };
+    // the load issued at step i serves step i+2, whose C phase stores row i-a: guide offset (i - a) * pitch_g
+    uint32_t gofs = (uint32_t)max(i - a, 0) * pitch_g;
+    // warm period: steps r_lo+1 .. r_lo+RC (slots 0 .. RC-1)
+    period(std::true_type{}, gofs);
+    // normal periods: band rows
+    for (int p = 0; p < g.band / RC; ++p) period(std::false_type{}, gofs);
+}
+
+
+template <int K, typename TOut>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_guided_split(const uint8_t *__restrict__ gray, const float *__restrict__ t0, TOut *__restrict__ tout, SplitGeom g, PipeConsts cs)
+{
+    extern __shared__ double2 lds_raw[];
+    char *lds = reinterpret_cast<char *>(lds_raw);
+    const int x_lo = (int)blockIdx.x * PipeCfg<K>::NV;
+    const bool edge = x_lo - 2 * PipeCfg<K>::a < 0 || x_lo - 2 * PipeCfg<K>::a + kPipeSlots > g.W;  // wave-uniform
+    if (edge) split_body<K, true, TOut>(gray, t0, tout, g, cs, lds);
+    else split_body<K, false, TOut>(gray, t0, tout, g, cs, lds);
+}
+
+template <int K, typename TOut>
+int launch_split(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, int y0, int band, int nbands,
+                 hipStream_t st)
+{
+    using C = PipeCfg<K>;
+    constexpr int lds = C::RC * (C::NL + 1) * 16 + (C::s1_doubles + C::s2_doubles) * 8;
+    SplitGeom g{s.H, s.W, y0, band};
+    const int nstrips = cdiv(s.W, C::NV);
+    {
+        UWIE_PROF("k_guided_split", st);
+        hipLaunchKernelGGL((k_guided_split<K, TOut>), dim3(nstrips, nbands, s.B), dim3(64), (size_t)lds, st, d_gray, d_t0, d_t, g, cs);
+    }
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+// border != nullptr: {iy0, iy1, iband, nibands, is0, is1}: the launch covers everything around the interior block
 template <int K, bool FX, typename TOut>
-int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, hipStream_t st)
+int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, hipStream_t st,
+                const int *border = nullptr)
 {
     using C = PipeCfg<K>;
     constexpr int lds = C::lds_bytes(FX);
@@ -586,10 +934,15 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
         nbands = std::min(nbands, std::max(cap, (int)cdiv((size_t)(3L * resident), (size_t)strips)));
     }
     nbands = std::max(1, std::min(nbands, s.H / std::max(64, 4 * K)));
-    PipeGeom g;
+    PipeGeom g{};
     g.H = s.H; g.W = s.W;
     g.band = cdiv(s.H, nbands);
-    const int gy = cdiv(s.H, g.band);
+    int gy = cdiv(s.H, g.band);
+    if (border) {
+        g.iy0 = border[0]; g.iy1 = border[1]; g.iband = border[2];
+        gy = 2 + border[3];
+        g.is0 = border[4]; g.is1 = border[5];
+    }
     {
         UWIE_PROF("k_guided_pipe", st);
         hipLaunchKernelGGL((k_guided_pipe<K, FX, TOut>), dim3(nstrips, gy, s.B), dim3(64), (size_t)lds, st, d_gray, d_t0, d_t, g, cs);
@@ -633,6 +986,35 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
         cs.kb = scale;
         cs.b0 = 0.0;
     }
+    // float64, k = 15: the split-ring kernel takes the rows whose windows touch neither the top nor the bottom image
+    // border (every strip), the general kernel the rows above and below.  UWIE_GF_SPLIT=0 (read per call) keeps one general launch.
+    const char *env_split = getenv("UWIE_GF_SPLIT");
+    if (ring == 0 && k == 15 && !(s.W & 1) && !(env_split && atoi(env_split) == 0)) {
+        using C = PipeCfg<15>;
+        const int iy0 = 2 * C::a;                                            // first band: raw rows from y - 2a >= 0
+        const int periods = (s.H - C::K_ - 1 - iy0) / C::RC;                 // last band: raw rows up to y_hi + K <= H - 1
+        if (periods >= 4) {
+            int nb;
+            const char *env_b = getenv("UWIE_GF_BANDS");
+            if (env_b) nb = atoi(env_b);
+            else {
+                // ~8 wavefronts per resident slot (256 CUs x 8) even out the tail; a band costs one extra ring period
+                const long strips = (long)cdiv(s.W, C::NV) * s.B;
+                nb = (int)cdiv((size_t)(8L * 2048), (size_t)strips);
+                nb = std::min(nb, std::max(1, periods / 12));  // ... but at least 12 periods (180 rows) long
+            }
+            nb = std::max(1, std::min(nb, periods));
+            const int band = C::RC * (periods / nb), iy1 = iy0 + nb * band;
+            // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
+            if (!env_b && (long)cdiv(s.W, C::NV) * s.B * nb < 1024) goto general;
+            const int border[6] = {iy0, iy1, band, 0, 0, 0};  // rows [0, iy0) and [iy1, H) of every strip
+            UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, st)));
+            UWIE_TRY_RC((launch_pipe<15, false, double>(d_gray, d_t0, s, cs, d_t, st, border)));
+            *handled = 1;
+            return UWIE_OK;
+        }
+    }
+general:
     int rc;
 #define UWIE_PIPE_CASE(KK)                                                                                   \
     case KK:                                                                                                 \
