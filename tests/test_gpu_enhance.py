@@ -282,12 +282,12 @@ def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
     dev.profile(True)
     uw.enhance(frames, strategy=2)
     every = dev.profile_rows()
-    assert "k_guided_wave" in every and len(every) > 10
-    dev.profile(True, only="k_guided_wave")
+    assert "k_guided_pipe" in every and len(every) > 10
+    dev.profile(True, only="k_guided_pipe")
     uw.enhance(frames, strategy=2)
     rows = dev.profile_rows()
     dev.profile(False)
-    assert list(rows) == ["k_guided_wave"] and rows["k_guided_wave"][1] == 1
+    assert list(rows) == ["k_guided_pipe"] and rows["k_guided_pipe"][1] == 1
     assert _lib.load().uwie_profile_filter(dev._ctx, None) == 0
 
 
