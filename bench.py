@@ -209,6 +209,89 @@ def extras(dev, args, torch, _lib):
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this script with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rendezvous on 127.0.0.1.  Returns the worst child exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
+def main_scatter(args, uw, _lib, torch, world, rank, local, rehearsal):
+    """BASELINE.json configs[3]: rank 0 holds world x batch frames in HBM; one step = scatter (point-to-point shards over
+    RCCL / xGMI) -> enhance on every rank -> gather on rank 0.  value = all frames / the slowest rank's time."""
+    import ctypes
+
+    import torch.distributed as dist
+
+    from underwater_image_enhancement_amd.distributed import comm_device, enhance_sharded, shard_range
+
+    dev = uw.get_device(local)
+    H, W, B = args.height, args.width, args.batch
+    total = B * world
+    cdev = comm_device() if world > 1 else dev.torch_device
+    frames = synth_frames(args.dist, total, H, W, dev.torch_device, seed=3000).to(cdev) if rank == 0 else None
+    p = dev.params(_lib.SURFACE_SIX, args.strategy)
+    lo, hi = shard_range(total, rank, world)
+    ws = dev.workspace_for(max(hi - lo, 1), H, W, p)
+    out = dev.empty((max(hi - lo, 1), H, W, 3), torch.uint8)
+
+    def compute(x):  # this rank's shard, on the communication device (HBM under RCCL)
+        xd = x.to(dev.torch_device)
+        n = int(xd.shape[0])
+        _lib.check(dev.lib.uwie_enhance_u8(dev._ctx, ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, n, H, W,
+                                           ctypes.byref(p), ctypes.c_void_p(ws.data_ptr()), ws.numel(), dev.stream()))
+        torch.cuda.current_stream().synchronize()
+        return out[:n].to(x.device)
+
+    def step():
+        if world == 1:
+            return compute(frames)
+        return enhance_sharded(frames, src=0, compute=compute)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank == 0:
+        assert res.shape[0] == total
+        print(json.dumps({
+            "metric": "megapixels/sec enhanced", "value": round(total * H * W * args.steps / elapsed / 1e6, 2),
+            "unit": "megapixels/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} RGB u8 ({args.dist}), {total} frames held by rank 0, scatter -> strategy{args.strategy} "
+                                   f"+ cast correction -> gather ({'gloo rehearsal' if rehearsal else 'RCCL point-to-point'}; "
+                                   "BASELINE.json configs[3] layout)",
+                       "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"scatter/gather x{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,9 +303,17 @@ def main():
     ap.add_argument("--strategy", type=int, default=2)
     ap.add_argument("--dist", choices=("underwater", "uniform", "hazy"), default="underwater",
                     help="synthetic input distribution (SURVEY.md section 8d); the headline number uses underwater")
+    ap.add_argument("--mode", choices=("local", "scatter"), default="local",
+                    help="local: every rank enhances frames it already holds (headline, weak scaling).  scatter: rank 0 holds the "
+                         "whole batch in HBM, each step = scatter over RCCL -> enhance -> gather (BASELINE.json configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other input distributions and the 1080p batch=1 case")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under torchrun: start one fresh process per GPU ourselves, BEFORE anything here touches the GPU (a process
+        # that has initialised HIP must not fork/exec workers), and hand back rank 0's line and the worst exit code.
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
 
@@ -245,7 +336,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
+                 f"{args.gpus} (or without a launcher: bench.py starts the ranks itself)")
+    if args.mode == "scatter":
+        return main_scatter(args, uw, _lib, torch, world, rank, local, rehearsal)
 
     dev = uw.get_device(local)
     H, W, B = args.height, args.width, args.batch

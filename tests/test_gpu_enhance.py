@@ -159,8 +159,14 @@ def test_dict_surface_error_behaviour(uw, orc):
     x = orc.normalise_u8(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8))
     with pytest.raises(ValueError):
         uw.EnhancementStrategies.apply_strategy(x, "weak_dehazing", {})  # commented out in the reference (ES:494-496)
-    bad = rng.random((16, 16, 3)).astype(np.float32)  # not u8-derived: swallowed, input returned (ES:503-508)
-    assert uw.EnhancementStrategies.apply_strategy(bad, "strong_dehazing", {}) is bad
+    # ES:503-508 swallows failures INSIDE a strategy and returns the input (here: a window wider than the frame)
+    assert uw.EnhancementStrategies.apply_strategy(x, "strong_dehazing", {"guided_radius": 4000}) is x
+    # ... but an image this build has no device path for (not u8-derived) is refused, never passed through as a success
+    bad = rng.random((16, 16, 3)).astype(np.float32)
+    with pytest.raises(uw.UnsupportedInputError):
+        uw.EnhancementStrategies.apply_strategy(bad, "strong_dehazing", {})
+    with pytest.raises(uw.UnsupportedInputError):
+        uw.SixStrategies.strategy2_medium_dehazing(bad)
 
 
 @pytest.mark.parametrize("strategy", [1, 2, 3])

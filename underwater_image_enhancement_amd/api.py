@@ -10,8 +10,10 @@ Reference surfaces mirrored here (same names, argument meaning and error behavio
 * ``EnhancementStrategies.apply_strategy(img, name, params)`` -- ``enhancement_strategies.py:477-508``.
 
 Float images handed to these functions must be u8-derived (``u8.astype(float32)/255`` possibly followed by
-``color_correction``), which is what every caller in the reference passes (``six_stadigy.py:406``,
-``main.py:108``): the device path starts from the u8 frame.  Anything else raises ``ValueError``.
+``color_correction``), which is what the reference's pipelines pass (``six_stadigy.py:406``, ``main.py:108``): the
+device path starts from the u8 frame.  Anything else raises ``UnsupportedInputError`` -- also from
+``apply_strategy``, whose swallow-and-return-the-input convention (ES:503-508) is for failures INSIDE a strategy:
+an input this build cannot process is never reported as a successful pass-through.
 """
 from __future__ import annotations
 
@@ -20,6 +22,10 @@ import torch
 
 from . import _lib
 from .runtime import Device, get_device
+
+class UnsupportedInputError(ValueError):
+    """The float image is not u8-derived: this build has no device path for it (see the module docstring)."""
+
 
 _F255 = np.float32(255.0)
 _ATTEN = np.float32(0.85)
@@ -218,7 +224,7 @@ def _recover_u8(img):
         raise ValueError("empty image")
     x32 = x.astype(np.float32)
     if x.dtype != np.float32 and not np.array_equal(x32.astype(x.dtype), x):
-        raise ValueError("float image is not float32-representable u8/255 data")
+        raise UnsupportedInputError("float image is not float32-representable u8/255 data")
     table = np.arange(256, dtype=np.float32) / _F255
     for kind, chan in (("normal", None), ("greenish", 1), ("bluish", 2)):
         ok, u8 = True, np.empty(x.shape, np.uint8)
@@ -231,7 +237,7 @@ def _recover_u8(img):
             u8[:, :, c] = idx
         if ok:
             return u8, kind
-    raise ValueError("float image is not u8-derived (u8/255, optionally colour-corrected): unsupported input")
+    raise UnsupportedInputError("float image is not u8-derived (u8/255, optionally colour-corrected): unsupported input")
 
 
 def detect_image_type(img, device: int | None = None) -> str:
@@ -305,6 +311,8 @@ class EnhancementStrategies:
             raise ValueError(f"未知策略: {strategy_name}")
         try:
             return cls._run(img, strategy_name, params)
+        except UnsupportedInputError:
+            raise  # not a strategy failure: never handed back as if it had been processed
         except Exception as exc:  # noqa: BLE001 - mirrors the reference's blanket except
             if not cls.swallow_errors:
                 raise

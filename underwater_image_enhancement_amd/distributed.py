@@ -27,6 +27,15 @@ def shard_range(n_frames: int, rank: int, world: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+def comm_device(backend: str | None = None) -> torch.device:
+    """The device every tensor handed to a collective must live on: the rank's current ROCm device under "nccl"
+    (= RCCL, which rejects CPU tensors), the CPU under "gloo".  The same on every rank, whoever holds the data."""
+    backend = backend or dist.get_backend()
+    if str(backend).lower() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def _meta(frames, src, device):
     """Broadcast (B, H, W) from the source rank."""
     shape = torch.zeros(3, dtype=torch.int64, device=device)
@@ -37,20 +46,24 @@ def _meta(frames, src, device):
 
 
 def scatter_frames(frames, src: int = 0, device=None):
-    """Rank ``src`` holds uint8 ``[B,H,W,3]``; every rank returns its shard (possibly 0 frames) on ``device``."""
+    """Rank ``src`` holds uint8 ``[B,H,W,3]`` (host or device memory); every rank returns its shard (possibly 0
+    frames) on ``device`` (default: the backend's device, ``comm_device()``: HBM under RCCL).  A host batch on the
+    root is moved to the communication device shard by shard, so the root never holds a second full copy."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    device = device or (frames.device if frames is not None else torch.device("cpu"))
+    device = torch.device(device) if device is not None else comm_device()
     B, H, W = _meta(frames, src, device)
     lo, hi = shard_range(B, rank, world)
     if rank == src:
-        reqs = []
+        reqs, keep = [], []
         for peer in range(world):
             if peer == src:
                 continue
             plo, phi = shard_range(B, peer, world)
             if phi > plo:
-                reqs.append(dist.isend(frames[plo:phi].contiguous(), dst=peer))
-        local = frames[lo:hi].contiguous()
+                shard = frames[plo:phi].to(device, non_blocking=True).contiguous()
+                keep.append(shard)  # alive until the send has completed
+                reqs.append(dist.isend(shard, dst=peer))
+        local = frames[lo:hi].to(device).contiguous()
         for r in reqs:
             r.wait()
         return local
@@ -61,8 +74,10 @@ def scatter_frames(frames, src: int = 0, device=None):
 
 
 def gather_frames(local, n_frames: int, dst: int = 0):
-    """Inverse of scatter_frames: rank ``dst`` returns ``[n_frames,H,W,3]``, the others ``None``."""
+    """Inverse of scatter_frames: rank ``dst`` returns ``[n_frames,H,W,3]`` (on the communication device), the
+    others ``None``."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    local = local.to(comm_device())
     if rank != dst:
         if local.shape[0] > 0:
             dist.send(local.contiguous(), dst=dst)
@@ -84,8 +99,9 @@ def gather_frames(local, n_frames: int, dst: int = 0):
 
 
 def enhance_sharded(frames, src: int = 0, compute=None, device=None, **kwargs):
-    """Root-held batch -> scatter -> per-rank enhance -> gather back to the root.  Returns the enhanced batch on
-    ``src`` and ``None`` elsewhere.  ``kwargs`` go to ``api.enhance`` (strategy, cast_correct, overrides)."""
+    """Root-held batch -> scatter -> per-rank enhance -> gather back to the root (BASELINE.json configs[3]).  Returns the
+    enhanced batch on ``src`` (on the communication device) and ``None`` elsewhere.  ``src`` is the rank that holds
+    ``frames`` (the other ranks pass ``None``); ``kwargs`` go to ``api.enhance`` (strategy, cast_correct, overrides)."""
     if compute is None:
         from .api import enhance
 
@@ -93,8 +109,13 @@ def enhance_sharded(frames, src: int = 0, compute=None, device=None, **kwargs):
             return enhance(x, **kwargs)
 
     rank = dist.get_rank()
-    n = [int(frames.shape[0]) if rank == src else 0]
-    dist.broadcast_object_list(n, src=src)
+    device = torch.device(device) if device is not None else comm_device()
+    n = torch.zeros(1, dtype=torch.int64, device=device)  # (a tensor broadcast: no pickling, no device guessing)
+    if rank == src:
+        n[0] = int(frames.shape[0])
+    dist.broadcast(n, src=src)
     local = scatter_frames(frames if rank == src else None, src=src, device=device)
     out = compute(local) if local.shape[0] > 0 else local
-    return gather_frames(out, n[0], dst=src)
+    if not torch.is_tensor(out):
+        out = torch.as_tensor(out)
+    return gather_frames(out, int(n[0]), dst=src)
