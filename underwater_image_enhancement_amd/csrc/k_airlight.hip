@@ -28,6 +28,7 @@ struct LevelBufs {
     Region *blk;       // [B] current block
     Region *regs;      // [4B] its quadrants (inactive when the block is a leaf)
     float *csum;       // [4B][maxChunks][3] chunk sums
+    float *csum_var;   // the same for the squared deviations
     float *tot;        // [4B][3] sums
     float *mean;       // [4B][3] means
     float *vtot;       // [4B][3] sums of squared deviations
@@ -213,10 +214,13 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
 }
 
 // One wavefront per (chunk, region).  csum[(reg*maxChunks + chunk)*3 + c] = pairwise sum of that chunk.
+// VAR with csum_in != nullptr: the means come from the chunk sums of the previous pass (added sequentially by lanes 0..2,
+// as k_q_combine would), so the quadtree needs no combine launch between its two passes.
 template <bool VAR>
 __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                      const Region *__restrict__ regs, const float *__restrict__ mean,
-                                                     int H, int W, int maxChunks, float *__restrict__ csum)
+                                                     int H, int W, int maxChunks, float *__restrict__ csum,
+                                                     const float *__restrict__ csum_in = nullptr)
 {
     const int reg = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
     const Region r = regs[reg];
@@ -232,9 +236,25 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     el.W = W;
     el.kind = kind ? kind[r.img] : 0;
     if (VAR) {
-        el.mean[0] = mean[reg * 3 + 0];
-        el.mean[1] = mean[reg * 3 + 1];
-        el.mean[2] = mean[reg * 3 + 2];
+        if (csum_in) {
+            // the chunk sums come into LDS with coalesced loads; lanes 0..2 then add them in order
+            extern __shared__ float cs_l[];
+            const int nch = (n + kNpChunk - 1) / kNpChunk;
+            for (int i = lane; i < nch * 3; i += 64) cs_l[i] = csum_in[(size_t)reg * maxChunks * 3 + i];
+            __syncthreads();
+            float acc = 0.0f;
+            if (lane < 3) {
+                for (int k = 0; k < nch; ++k) acc = acc + cs_l[k * 3 + lane];
+                acc = (float)((double)acc / (double)n);  // numpy/_core/_methods.py:_mean
+            }
+            el.mean[0] = __shfl(acc, 0);
+            el.mean[1] = __shfl(acc, 1);
+            el.mean[2] = __shfl(acc, 2);
+        } else {
+            el.mean[0] = mean[reg * 3 + 0];
+            el.mean[1] = mean[reg * 3 + 1];
+            el.mean[2] = mean[reg * 3 + 2];
+        }
     }
     float *out = csum + ((size_t)reg * maxChunks + ci) * 3;
 
@@ -282,20 +302,50 @@ __global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ reg
 // compute_Q's final arithmetic (six_stadigy.py:134-155) and the greedy step (six_stadigy.py:100-111).
 // It also prepares the next level: the chosen block's quadrants (what k_make_quadrants would write) and zeroed edge
 // counters, so a level costs two launches fewer.
-__global__ void k_q_select(Region *__restrict__ blk, Region *__restrict__ regs, const float *__restrict__ tot,
-                           const float *__restrict__ vtot, uint32_t *__restrict__ edges, int B, int level, int min_size,
-                           TraceRec *__restrict__ trace)
+// One wavefront per image.  The totals are the sequential sums of the chunk sums (NumPy adds each buffer's pairwise
+// result into the running total): lane q*6 + pass*3 + c does that for quadrant q, pass (0 sums, 1 squared deviations)
+// and channel c, so no combine launch is needed either.
+__global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Region *__restrict__ regs,
+                                                 const float *__restrict__ csum, const float *__restrict__ csum_var, int maxChunks,
+                                                 uint32_t *__restrict__ edges, int B, int level, int min_size,
+                                                 TraceRec *__restrict__ trace)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (regs[b * 4].rows == 0) return;  // leaf reached earlier
+    extern __shared__ float cs_l[];  // [4 quadrants][2 passes][nchMax * 3]
+    int nchMax = 0;
+    for (int q = 0; q < 4; ++q) {
+        const Region r = regs[b * 4 + q];
+        nchMax = max(nchMax, (r.rows * r.cols + kNpChunk - 1) / kNpChunk);
+    }
+    for (int q = 0; q < 4; ++q) {
+        const Region r = regs[b * 4 + q];
+        const int nch = (r.rows * r.cols + kNpChunk - 1) / kNpChunk;
+        for (int i = lane; i < nch * 3; i += 64) {
+            cs_l[(q * 2 + 0) * nchMax * 3 + i] = csum[(size_t)(b * 4 + q) * maxChunks * 3 + i];
+            cs_l[(q * 2 + 1) * nchMax * 3 + i] = csum_var[(size_t)(b * 4 + q) * maxChunks * 3 + i];
+        }
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    if (lane < 24) {
+        const int q = lane / 6, pass = (lane % 6) / 3, c = lane % 3;
+        const Region r = regs[b * 4 + q];
+        const int n = r.rows * r.cols, nch = (n + kNpChunk - 1) / kNpChunk;
+        const float *cs = cs_l + (q * 2 + pass) * nchMax * 3 + c;
+        for (int k = 0; k < nch; ++k) acc = acc + cs[k * 3];
+    }
+    float tots[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) tots[i] = __shfl(acc, i);
+    if (lane != 0) return;
     double best = 0.0;
     int arg = 0;
     double score[4];
     for (int q = 0; q < 4; ++q) {
         const Region r = regs[b * 4 + q];
         const long long n = (long long)r.rows * r.cols;
-        const float *S = tot + (b * 4 + q) * 3, *V = vtot + (b * 4 + q) * 3;
+        const float *S = tots + q * 6, *V = tots + q * 6 + 3;
         const float t1 = ((S[0] + S[1]) + S[2]) / (float)(3 * n);
         const float t2 = ((S[2] + S[1]) - 2.0f * S[0]) / (float)n;
         const float v0 = V[0] / (float)n, v1 = V[1] / (float)n, v2 = V[2] / (float)n;
@@ -365,6 +415,7 @@ LevelBufs carve_level(Carver &c, Shape s)
     L.blk = c.take<Region>(s.B);
     L.regs = c.take<Region>(nreg);
     L.csum = c.take<float>(nreg * max_chunks(s) * 3);
+    L.csum_var = c.take<float>(nreg * max_chunks(s) * 3);
     L.tot = c.take<float>(nreg * 3);
     L.mean = c.take<float>(nreg * 3);
     L.vtot = c.take<float>(nreg * 3);
@@ -383,11 +434,13 @@ int launch_region_stats(const uint8_t *d_in, const int32_t *d_kind, const Region
 {
     const int nch = cdiv((long long)max_rows * max_cols, kNpChunk);
     UWIE_REQUIRE(nch <= maxChunks, "region_stats: scratch too small");
-    UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
+    UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum,
+                (const float *)nullptr);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, tot, mean);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum);
+    UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum,
+                (const float *)nullptr);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, vtot, mean);
     UWIE_LAUNCH_CHECK();
@@ -420,22 +473,17 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
     for (int level = 0; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
         const int nch = cdiv((long long)qr * qc, kNpChunk);
+        // sums -> squared deviations (means derived in the kernel) -> Canny -> select (totals derived in the kernel)
         UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
-                           s.W, maxChunks, L.csum);
+                           s.W, maxChunks, L.csum, (const float *)nullptr);
         UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, L.regs, L.csum, nreg,
-                           maxChunks, L.tot, L.mean);
-        UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
-                           s.W, maxChunks, L.csum);
-        UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, L.regs, L.csum, nreg,
-                           maxChunks, L.vtot, L.mean);
+        UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), sizeof(float) * 3 * nch, st, d_in, d_kind, L.regs, L.mean, s.H,
+                           s.W, maxChunks, L.csum_var, (const float *)L.csum);
         UWIE_LAUNCH_CHECK();
         int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
         if (rc != UWIE_OK) return rc;
-        UWIE_LAUNCH(k_q_select, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, L.tot, L.vtot, L.edges, B,
-                           level, min_size, (TraceRec *)d_trace);
+        UWIE_LAUNCH(k_q_select, dim3(B), dim3(64), sizeof(float) * 24 * nch, st, L.blk, L.regs, (const float *)L.csum, (const float *)L.csum_var,
+                           maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
         cmax = qc;

@@ -12,6 +12,10 @@
 //                  direction class and non-maximum suppression with OpenCV's fixed-point tan(22.5 deg) for its 8 pixels.
 //                  Writes the map byte {weak, none, strong} of every pixel and the candidates (weak | strong) of each
 //                  (tile, wavefront) into that wavefront's own list slot: no atomics, no second barrier.
+//   k_canny_gradnms<true> (optional pre-pass, same tiles): gradient magnitudes only -> strong[region] = 1 if any pixel of
+//                  the region exceeds the HIGH threshold.  Hysteresis keeps exactly the components that own such a
+//                  pixel, so a region without one has no edge at all and its tiles skip everything else (smooth
+//                  water: the sensor noise crosses the low threshold everywhere and the high one nowhere).
 //   k_canny_union  8-connected components of the candidates: lock-free union-find on pixel indices (links always point
 //                  to the smaller index; agent-scope atomics, so XCD placement is irrelevant)
 //   k_canny_mark   walks the tile-local ROOTS only (k_canny_gradnms records each with its component's size and number of
@@ -24,6 +28,8 @@
 // strong one), so the component formulation equals OpenCV's stack-based flood fill.
 #include "common.h"
 #include "devutil.h"
+
+#include <cstdlib>
 
 namespace uwie {
 
@@ -38,6 +44,7 @@ struct CannyBufs {
     uint2 *roots;      // tile-local component roots, same slots: {pixel index of the root, size | strong pixels << 16}
     uint32_t *nroot;   // their counts, [tile][4]
     uint32_t *nborder; // candidates on the tile's left / right column or bottom row: they lead their list, [tile][4]
+    uint32_t *strong;  // [region] some pixel's gradient magnitude exceeds the high threshold (pre-pass), or nullptr
     int tiles;         // tiles per region in this launch
 };
 
@@ -89,6 +96,7 @@ __device__ void lds_union(uint32_t *L, int a, int b)
     }
 }
 
+template <bool PRE>
 __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
                                                        int H, int W, int tiles_x, int low, int high, CannyBufs bufs)
 {
@@ -101,8 +109,8 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     const int tid = threadIdx.x;
     if (tid == 0) s_total = 0;  // (the barrier after the tile fill orders this before the atomics)
     const size_t sub = ((size_t)blockIdx.y * bufs.tiles + blockIdx.x) * 4 + (tid >> 6);  // this wavefront's list
-    if (ty0 >= r.rows || tx0 >= r.cols) {
-        if ((tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = bufs.nborder[sub] = 0;
+    if (ty0 >= r.rows || tx0 >= r.cols || (!PRE && bufs.strong && !bufs.strong[blockIdx.y])) {
+        if (!PRE && (tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = bufs.nborder[sub] = 0;
         return;
     }
     const size_t base = (size_t)r.img * H * W;
@@ -169,6 +177,15 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
                 if (!(rowin && mx >= 0 && mx < r.cols)) mag[mr][mc] = 0;
             }
         }
+    }
+    if constexpr (PRE) {
+        int top = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) top = max(top, mag[i + 1][j + 1]);
+        if (__ballot(top > high) && (tid & 63) == 0) bufs.strong[blockIdx.y] = 1;
+        return;
     }
     // non-maximum suppression, branch-free: the two neighbours along the gradient direction are selected, not branched on
     uint32_t cls[2] = {0x01010101u, 0x01010101u}, keepmask = 0;
@@ -491,6 +508,7 @@ CannyBufs carve_canny(Carver &c, Shape s)
     b.roots = c.take<uint2>(canny_list_tiles(s) * 2048);
     b.nroot = c.take<uint32_t>(canny_list_tiles(s) * 4);
     b.nborder = c.take<uint32_t>(canny_list_tiles(s) * 4);
+    b.strong = c.take<uint32_t>((size_t)s.B * 4);
     return b;
 }
 
@@ -525,7 +543,16 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     const dim3 lgrid(cdiv(cdiv(bufs.tiles, kWalkTiles), 4), nreg);  // list walkers: 4 wavefronts per block
     if (d_count && !count_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
-    UWIE_LAUNCH(k_canny_gradnms, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+    // Pre-pass (edge counts only: the standalone edge map keeps the single pass): regions without a pixel above the high
+    // threshold have no edges.  UWIE_CANNY_PREPASS=0 (read per call) disables it.
+    const char *env_pre = getenv("UWIE_CANNY_PREPASS");
+    if (d_edges || nreg > s.B * 4 || (env_pre && atoi(env_pre) == 0)) bufs.strong = nullptr;
+    if (bufs.strong) {
+        UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
+        UWIE_LAUNCH(k_canny_gradnms<true>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+        UWIE_LAUNCH_CHECK();
+    }
+    UWIE_LAUNCH(k_canny_gradnms<false>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_canny_union, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
     UWIE_LAUNCH_CHECK();
