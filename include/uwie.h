@@ -76,7 +76,17 @@ typedef struct uwie_params {
     int32_t gf_exact;      /* guided filter: 1 = reproduce cv2.boxFilter's float64 running-sum order bit for
                               bit (6 materialised planes); 0 (default) = fused single-kernel float64 filter,
                               same window/border, free summation order: |t - t_exact| <= 1e-11            */
+    int32_t inter_dtype;   /* number format of the guided filter's a/b intermediates (S6:39-43) when gf_exact = 0:
+                              UWIE_INTER_F64 (default) float64 like the reference; UWIE_INTER_FX32 32-bit fixed
+                              point (BASELINE.json configs[4] "reduced-precision intermediates": a and b are rounded
+                              once to 2^-31 / 2^-30, every sum stays exact; |t - t_exact| <= 5e-10; u8 output: about
+                              one byte in 1e6-1e7 differs, by 1 LSB before CLAHE and up to CLAHE's local slope
+                              after it -- tests/test_gpu_fuzz.py).  SIX surface only (needs the pre-clipped transmission, S6:174); other
+                              cases silently keep float64.                                                */
 } uwie_params;
+
+#define UWIE_INTER_F64 0
+#define UWIE_INTER_FX32 1
 
 const char *uwie_last_error(void);
 const char *uwie_version(void);
@@ -113,6 +123,17 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p);
  */
 int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float *d_out_f32, int batch, int H, int W,
                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The dict surface with the reference's own result type: recover_image / clahe_enhancement / histogram_equalization /
+ * color_enhancement / gamma_correction return float64 (ES:247,307,345,269-270,284-285), and the caller quantises THAT
+ * ((enhanced * 255).astype(np.uint8), main.py:155).  d_out_f64: [batch][H][W][3] float64; d_out_u8 (optional) the device's
+ * own quantisation of the same values.  UWIE_SURFACE_DICT only; same workspace as uwie_enhance_u8. */
+int uwie_enhance_u8_f64(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, double *d_out_f64, int batch, int H, int W,
+                        const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Scratch bytes uwie_enhance_all_u8 needs for these six parameter sets (NULL = the defaults): one layout sized for the
+ * most demanding of them (exact-order guided filter planes, widest CLAHE tile grid). */
+size_t uwie_workspace_bytes_all(int batch, int H, int W, const uwie_params *p6);
 
 /*
  * The batch driver's inner loop (six_stadigy.py:398-431): one cast detection / correction per image, then all six
@@ -186,7 +207,9 @@ int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
 int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int batch, int H, int W, int ksize,
                         void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* guided_filter(gray/255, t0, r, eps) followed by clip(.,0.1,1) (S6:178-180, ES:229-232): float64 [batch][H][W]. */
+/* guided_filter(gray/255, t0, r, eps) followed by clip(.,0.1,1) (S6:178-180, ES:229-232): float64 [batch][H][W].
+ * `exact`: 0 = fused float64 kernels (uwie_params.gf_exact = 0), 1 = cv2.boxFilter's running-sum order, 2 = fused with
+ * the fixed-point a/b ring (uwie_params.inter_dtype = UWIE_INTER_FX32; the caller guarantees 0.1 <= t0 <= 1). */
 int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
                        double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
 

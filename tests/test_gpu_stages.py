@@ -198,6 +198,36 @@ def test_transmission_init_and_guided_filter(dev, orc, frames):
             # default fused filter: same windows and borders, free float64 summation order.  Tolerance: 1e-11 absolute
             tf = dev.guided_filter(gray, t0, ks, eps, exact=False)[0].cpu().numpy()
             assert tf.dtype == np.float64 and np.abs(tf - want_t).max() <= 1e-11, (name, ks, np.abs(tf - want_t).max())
+            # reduced-precision intermediates (uwie_params.inter_dtype = UWIE_INTER_FX32, BASELINE.json configs[4]): a and b
+            # enter the ring as 32-bit fixed point.  Tolerance: 5e-10 absolute on t (k = 10 averages the fewest roundings)
+            tx = dev.guided_filter(gray, t0, ks, eps, exact=2)[0].cpu().numpy()
+            assert tx.dtype == np.float64 and np.abs(tx - want_t).max() <= 5e-10, (name, ks, np.abs(tx - want_t).max())
+
+
+@pytest.mark.parametrize("shape,bands", [((260, 700), 2), ((181, 256), 1), ((333, 490), 3)])
+def test_split_ring_guided_filter(dev, orc, monkeypatch, shape, bands):
+    """The split-ring kernel (k = 15: a in LDS, b in registers, steady loop unrolled over the ring period) with the general
+    pipelined kernel on the rows above and below it.  Production takes it for large batches only (4K x 64: the full-size
+    tests and bench.py); here UWIE_GF_BANDS forces it on small frames so that the oracle comparison covers every part of
+    it: edge strips (reflected columns, mirrored a/b), interior strips, a ragged last strip, several bands, the border
+    rows.  Same tolerance as every float64 ring: 1e-11 absolute on t."""
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    B = 2
+    gray = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
+    gray[1] = (np.add.outer(np.arange(H), 2 * np.arange(W)) % 256).astype(np.uint8)
+    t0 = np.clip(rng.random((B, H, W), dtype=np.float32), 0.1, 1.0)
+    monkeypatch.setenv("UWIE_GF_BANDS", str(bands))
+    for eps in (0.5, 1e-3):
+        got = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), 15, eps, exact=False).cpu().numpy()
+        for b in range(B):
+            want = np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], 15, eps), 0.1, 1.0)
+            err = np.abs(got[b] - want).max()
+            assert err <= 1e-11, (shape, bands, eps, b, err)
+    monkeypatch.setenv("UWIE_GF_SPLIT", "0")  # the general kernel alone gives the same answer to the same tolerance
+    alone = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), 15, 0.5, exact=False).cpu().numpy()
+    assert np.abs(alone - np.stack([np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], 15, 0.5), 0.1, 1.0)
+                                    for b in range(B)])).max() <= 1e-11
 
 
 @pytest.mark.parametrize("k", [15, 20, 10, 7])

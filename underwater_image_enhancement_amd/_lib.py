@@ -46,6 +46,7 @@ class UwieParams(ctypes.Structure):
         ("gamma", ctypes.c_double),
         ("apply_gamma", ctypes.c_int32),
         ("gf_exact", ctypes.c_int32),
+        ("inter_dtype", ctypes.c_int32),
     ]
 
 
@@ -63,7 +64,9 @@ SIGNATURES = {
     "uwie_profile_row": [_VP, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_D), ctypes.POINTER(_I)],
     "uwie_params_init": [_PP, _I, _I],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
+    "uwie_workspace_bytes_all": [_I, _I, _I, _VP],
     "uwie_enhance_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
+    "uwie_enhance_u8_f64": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_all_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP],
     "uwie_diff_enhance_f32": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _SZ, _VP],
     "uwie_extract_features_u8": [_VP, _VP, _VP, _I, _I, _I, _VP, _SZ, _VP],
@@ -91,6 +94,7 @@ _RESTYPES = {
     "uwie_version": ctypes.c_char_p,
     "uwie_destroy": None,
     "uwie_workspace_bytes": ctypes.c_size_t,
+    "uwie_workspace_bytes_all": ctypes.c_size_t,
 }
 
 _lib = None

@@ -334,5 +334,7 @@ class EnhancementStrategies:
             over["tiles_x"], over["tiles_y"] = (int(v) for v in params["tile_grid_size"])
         over["apply_gamma"] = int(bool(params.get("apply_gamma", False)))
         p = dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], **over)
-        _, outf = dev.enhance_u8(dev.tensor(u8[None]), p, want_float=True)
+        # float64 like the reference (ES:247,307,345): a caller's (enhanced * 255).astype(np.uint8) (main.py:155) then
+        # truncates the same values as with the reference
+        _, outf = dev.enhance_u8_f64(dev.tensor(u8[None]), p)
         return outf[0].cpu().numpy()

@@ -105,11 +105,31 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     return P;
 }
 
+// A parameter set whose carve_pipe layout holds every one of `n` six_stadigy sets (uwie_enhance_all_u8 runs them from
+// one workspace): dehazing layout, the exact-order guided filter's planes if any dehazing set needs them (gf_exact, or
+// a window the fused kernels do not take), the largest CLAHE tile grid.
+uwie_params merged_params(const uwie_params *ps, int n, Shape s)
+{
+    uwie_params m = ps[0];
+    m.surface = UWIE_SURFACE_SIX;
+    m.strategy = 2;
+    for (int i = 0; i < n; ++i) {
+        if (ps[i].tiles_x > m.tiles_x) m.tiles_x = ps[i].tiles_x;
+        if (ps[i].tiles_y > m.tiles_y) m.tiles_y = ps[i].tiles_y;
+        if (ps[i].surface == UWIE_SURFACE_SIX && ps[i].strategy <= 3 &&
+            (ps[i].gf_exact || !guided_fast_handles(s, ps[i].gf_ksize)))
+            m.gf_exact = 1;
+    }
+    return m;
+}
+
 int stage_guided(const Pipe &P, Shape s, const uwie_params *p, hipStream_t st)
 {
     int handled = 0;
-    const char *env_ring = getenv("UWIE_GF_RING");  // read per call
-    const bool fx = p->surface == UWIE_SURFACE_SIX && env_ring && atoi(env_ring) == 1;
+    // fixed-point a/b ring: only with the pre-clipped transmission of the six_stadigy surface (0.1 <= t0 <= 1 bounds a, b).
+    // UWIE_GF_RING=1 (read per call, experiments) forces it like inter_dtype = UWIE_INTER_FX32.
+    const char *env_ring = getenv("UWIE_GF_RING");
+    const bool fx = p->surface == UWIE_SURFACE_SIX && (p->inter_dtype == UWIE_INTER_FX32 || (env_ring && atoi(env_ring) == 1));
     if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, fx));
     if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
     return UWIE_OK;
@@ -204,7 +224,7 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
 
 // enhancement_strategies.py apply_strong/medium/light (ES:350-444) on the uncorrected frame
 int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
-                    float *d_out_f32, hipStream_t st)
+                    float *d_out_f32, hipStream_t st, double *d_out_f64 = nullptr)
 {
     UWIE_TRY(launch_quant_gray(d_in, nullptr, P.gray, s, p->gray_shift, st));
     UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
@@ -233,7 +253,8 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
         UWIE_TRY(select_lin_run64(plan, P.F64, s, st, recompute ? &src : nullptr));
     }
     UWIE_TRY(select_lerp64(plan, s, P.pct64, st));
-    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st, recompute ? &src : nullptr);
+    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, d_out_u8, d_out_f32, st, recompute ? &src : nullptr,
+                               d_out_f64);
 }
 
 int check_params(const uwie_params *p)
@@ -247,6 +268,12 @@ int check_params(const uwie_params *p)
     UWIE_REQUIRE(p->min_size >= 1, "min_size must be >= 1");
     UWIE_REQUIRE(p->tiles_x >= 1 && p->tiles_y >= 1 && p->tiles_x * p->tiles_y <= 4096, "bad CLAHE tile grid");
     if (dehazes(p)) UWIE_REQUIRE(p->gf_ksize >= 1 && p->gf_ksize <= 1024, "guided-filter width out of range");
+    // np.percentile raises ValueError("Percentiles must be in the range [0, 100]") for these (also for NaN)
+    UWIE_REQUIRE(p->L_low >= 0.0 && p->L_low <= 100.0 && p->L_high >= 0.0 && p->L_high <= 100.0,
+                 "L_low / L_high must be percentiles in [0, 100]");
+    if (p->surface == UWIE_SURFACE_SIX && (p->strategy >= 3 && p->strategy <= 5))
+        UWIE_REQUIRE(p->wb_percentile >= 0.0 && p->wb_percentile <= 100.0, "wb_percentile must be in [0, 100]");
+    UWIE_REQUIRE(p->inter_dtype == UWIE_INTER_F64 || p->inter_dtype == UWIE_INTER_FX32, "unknown inter_dtype");
     return UWIE_OK;
 }
 
@@ -427,10 +454,26 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
     return pipe > stage ? pipe : stage;
 }
 
+size_t uwie_workspace_bytes_all(int batch, int H, int W, const uwie_params *p6)
+{
+    if (!shape_ok(batch, H, W)) return 0;
+    uwie_params P6[6];
+    for (int k = 0; k < 6; ++k) {
+        if (p6) P6[k] = p6[k];
+        else if (uwie_params_init(&P6[k], UWIE_SURFACE_SIX, k + 1) != UWIE_OK) return 0;
+    }
+    const Shape s{batch, H, W};
+    const uwie_params Pm = merged_params(P6, 6, s);
+    Carver c(nullptr);
+    carve_pipe(c, s, &Pm);
+    return c.total();
+}
+
 int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float *d_out_f32, int batch, int H, int W,
                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && (d_out_u8 || d_out_f32), "enhance: NULL context or image pointer");
+    UWIE_HIP_CHECK(hipSetDevice(ctx->device));  // kernels, events and helper streams belong to the context's device
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_TRY(check_params(p));
     const Shape s{batch, H, W};
@@ -452,8 +495,8 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
             b0 += cnt[i];
             Carver ci(static_cast<char *>(d_workspace) + off);
             Ps[i] = carve_pipe(ci, Shape{cnt[i], H, W}, p);
+            if (off + ci.total() > workspace_bytes) fits_ws = false;  // (UWIE_STREAMS may have changed since the sizing call)
             off = (off + ci.total() + 255) & ~(size_t)255;
-            if (off > workspace_bytes + 255) fits_ws = false;
         }
         if (fits_ws) {
             if (!ctx->aux_ready) {
@@ -491,10 +534,28 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
     return run_dict_dehaze(ctx, d_in, s, p, P, d_out_u8, d_out_f32, st);
 }
 
+int uwie_enhance_u8_f64(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, double *d_out_f64, int batch, int H, int W,
+                        const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && d_out_f64, "enhance_f64: NULL context or image pointer");
+    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_TRY(check_params(p));
+    UWIE_REQUIRE(p->surface == UWIE_SURFACE_DICT, "enhance_f64: float64 images are the dict surface's (ES:247,307,345)");
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    Pipe P = carve_pipe(c, s, p);
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    if (!dehazes(p)) return launch_code_strategy(ctx, d_in, nullptr, s, p, d_out_u8, nullptr, P.scratch, st, d_out_f64);
+    return run_dict_dehaze(ctx, d_in, s, p, P, d_out_u8, nullptr, st, d_out_f64);
+}
+
 int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, int32_t *d_kind, int batch, int H, int W,
                         const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_out_u8, "enhance_all: NULL context or image pointer");
+    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
     UWIE_CHECK_SHAPE(batch, H, W);
     uwie_params P6[6];
     for (int k = 0; k < 6; ++k) {
@@ -508,7 +569,8 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
     }
     const Shape s{batch, H, W};
     Carver c(d_workspace);
-    Pipe P = carve_pipe(c, s, &P6[0]);  // a dehazing strategy's layout covers the other five
+    const uwie_params Pm = merged_params(P6, 6, s);
+    Pipe P = carve_pipe(c, s, &Pm);  // a dehazing layout sized for the most demanding of the six sets
     UWIE_CHECK_WS(c.total());
     hipStream_t st = (hipStream_t)stream;
     const int32_t *kind = nullptr;
@@ -634,8 +696,9 @@ int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, 
     UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "guided_filter: ksize out of range");
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(guided_ws_bytes(s));
+    UWIE_REQUIRE(exact >= 0 && exact <= 2, "guided_filter: mode is 0 (fused float64), 1 (exact order) or 2 (fixed-point ring)");
     int handled = 0;
-    if (!exact) UWIE_TRY(launch_guided_fast(d_gray, d_t0, s, ksize, eps, d_t, &handled, (hipStream_t)stream));
+    if (exact != 1) UWIE_TRY(launch_guided_fast(d_gray, d_t0, s, ksize, eps, d_t, &handled, (hipStream_t)stream, exact == 2));
     if (handled) return UWIE_OK;
     return launch_guided(d_gray, d_t0, s, ksize, eps, d_t, d_workspace, (hipStream_t)stream);
 }

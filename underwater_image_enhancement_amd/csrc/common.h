@@ -302,13 +302,14 @@ int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const do
                                  uint32_t *d_ghist, hipStream_t st, bool linear = false, const uint32_t *d_only = nullptr,
                                  const SelectPlan *plan = nullptr);
 int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
-                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src = nullptr);
+                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src = nullptr,
+                        double *d_out_f64 = nullptr);
 
 // k_codes.hip: strategies 4-6 of six_stadigy.py and the clahe / histogram-equalisation strategies of
 // enhancement_strategies.py, evaluated on 8-bit codes (per image and channel LUT chains + histograms)
 size_t codes_ws_bytes(Shape s, int tx, int ty);
 int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
-                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st);
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64 = nullptr);
 
 // k_tail.hip
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,

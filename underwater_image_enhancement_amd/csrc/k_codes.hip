@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *ws
 template <typename T>
 __global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__ hist, const int32_t *__restrict__ kind,
                                                     ChainProg prog, uint8_t *__restrict__ lut_code,
-                                                    float *__restrict__ lut_val)
+                                                    float *__restrict__ lut_val, double *__restrict__ lut_val64 = nullptr)
 {
     __shared__ uint32_t wsum[4], eqh[256], total_px;
     __shared__ T os[4];
@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__
     }
     if (lut_code) lut_code[(size_t)(b * 3 + c) * 256 + u] = (uint8_t)code;
     if (lut_val) lut_val[(size_t)(b * 3 + c) * 256 + u] = (float)val;
+    if (lut_val64) lut_val64[(size_t)(b * 3 + c) * 256 + u] = (double)val;
 }
 
 // ------------------------------------------------------------------ frame kernels
@@ -176,7 +177,9 @@ __global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__
 // u8 HWC codes -> outputs through per-(image, channel) LUTs.  grid (n, B)
 __global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ codes, const uint8_t *__restrict__ fin_code,
                                                     const float *__restrict__ fin_val, int npx,
-                                                    uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
+                                                    uint8_t *__restrict__ out_u8, float *__restrict__ out_f32,
+                                                    const double *__restrict__ fin_val64 = nullptr,
+                                                    double *__restrict__ out_f64 = nullptr)
 {
     __shared__ float s_ff[768];
     __shared__ uint8_t s_fu[768];
@@ -211,6 +214,15 @@ __global__ void __launch_bounds__(256) k_apply_lut3(const uint8_t *__restrict__ 
                     o[3 * i + 1] = s_ff[g[i]];
                     o[3 * i + 2] = s_ff[bl[i]];
                 }
+            }
+        }
+        if (out_f64) {  // the dict surface's float64 image (enhancement_strategies.py:307,345): straight from the table
+            double *o = out_f64 + base + (size_t)p * 3;
+            const double *tb = fin_val64 + (size_t)b * 768;
+            for (int i = 0; i < n; ++i) {
+                o[3 * i] = tb[r[i]];
+                o[3 * i + 1] = tb[g[i]];
+                o[3 * i + 2] = tb[bl[i]];
             }
         }
         if (out_u8) {
@@ -271,6 +283,7 @@ struct CodeBufs {
     uint8_t *lut_a_code;           // code LUT feeding CLAHE
     uint8_t *fin_code;
     float *fin_val;
+    double *fin_val64;
     uint8_t *tile_lut, *lab, *codes;
 };
 
@@ -283,6 +296,7 @@ CodeBufs carve_codes(Carver &c, Shape s, int tx, int ty)
     b.lut_a_code = c.take<uint8_t>((size_t)s.B * 768);
     b.fin_code = c.take<uint8_t>((size_t)s.B * 768);
     b.fin_val = c.take<float>((size_t)s.B * 768);
+    b.fin_val64 = c.take<double>((size_t)s.B * 768);
     b.tile_lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
     b.lab = c.take<uint8_t>(n3);
     b.codes = c.take<uint8_t>(n3);
@@ -315,7 +329,7 @@ int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_
 
 // u8 quantisation, eps 1e-10, gamma = clip(x**(1/g))); otherwise S6 arithmetic (float32, eps 1e-6, x**g).
 int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
-                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st)
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64)
 {
     Carver c(ws);
     const int tx = p->tiles_x, ty = p->tiles_y;
@@ -374,9 +388,13 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     }
     post.ops[post.nops++] = simple_op(OP_QUANT);
 
+    if (d_out_f64 && !es) {
+        set_error("float64 output is the dict surface's (enhancement_strategies.py returns float64)");
+        return UWIE_E_INVALID;
+    }
     auto run_chain = [&](const ChainProg &prog, const uint32_t *hist, const int32_t *kind, uint8_t *lc, float *lv) -> int {
-        if (es) UWIE_LAUNCH(k_code_chain<double>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv);
-        else UWIE_LAUNCH(k_code_chain<float>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv);
+        if (es) UWIE_LAUNCH(k_code_chain<double>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv, lv ? B.fin_val64 : (double *)nullptr);
+        else UWIE_LAUNCH(k_code_chain<float>, dim3(3, s.B), blk, 0, st, hist, kind, prog, lc, lv, (double *)nullptr);
         UWIE_LAUNCH_CHECK();
         return UWIE_OK;
     };
@@ -384,7 +402,8 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     if (!clahe) {
         int rc = run_chain(post, B.hist_in, d_kind, B.fin_code, B.fin_val);
         if (rc != UWIE_OK) return rc;
-        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, d_in, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32);
+        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, d_in, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32,
+                    (const double *)B.fin_val64, d_out_f64);
         UWIE_LAUNCH_CHECK();
         return UWIE_OK;
     }
@@ -398,7 +417,8 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
         if (rc != UWIE_OK) return rc;
         rc = run_chain(post, B.hist_mid, nullptr, B.fin_code, B.fin_val);
         if (rc != UWIE_OK) return rc;
-        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, B.codes, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32);
+        UWIE_LAUNCH(k_apply_lut3, gpx, blk, 0, st, B.codes, B.fin_code, B.fin_val, (int)n, d_out_u8, d_out_f32,
+                    (const double *)B.fin_val64, d_out_f64);
         UWIE_LAUNCH_CHECK();
         return UWIE_OK;
     }

@@ -716,7 +716,8 @@ struct StretchDiv64 {
 template <bool SRC>
 __global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict__ planar, RestoreSrc S,
                                                        const double *__restrict__ pct, int npx, int apply_gamma, double gexp,
-                                                       uint8_t *__restrict__ out_u8, float *__restrict__ out_f32)
+                                                       uint8_t *__restrict__ out_u8, float *__restrict__ out_f32,
+                                                       double *__restrict__ out_f64)
 {
     const int b = blockIdx.y;
     double lo[3];
@@ -742,7 +743,7 @@ __global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict_
                 for (int i = 0; i < 4; ++i) v[c][i] = i < n ? r[(size_t)c * npx + p + i] : 0.0;
         }
         uint32_t q[3][4];
-        float f[3][4];
+        double f[3][4];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -750,15 +751,21 @@ __global__ void __launch_bounds__(256) k_stretch64_out(const double *__restrict_
                 double y = fmin(fmax(den[c].quot(v[c][i] - lo[c]), 0.0), 1.0);
                 if (apply_gamma) y = fmin(fmax(pow(y, gexp), 0.0), 1.0);
                 q[c][i] = (uint32_t)((int)(y * 255.0) & 0xff);
-                f[c][i] = (float)y;
+                f[c][i] = y;
             }
         const size_t o = ((size_t)b * npx + p) * 3;
         if (out_u8) store_px4(out_u8 + o, q[0], q[1], q[2], n, aligned);
         if (out_f32)
             for (int i = 0; i < n; ++i) {
-                out_f32[o + 3 * i] = f[0][i];
-                out_f32[o + 3 * i + 1] = f[1][i];
-                out_f32[o + 3 * i + 2] = f[2][i];
+                out_f32[o + 3 * i] = (float)f[0][i];
+                out_f32[o + 3 * i + 1] = (float)f[1][i];
+                out_f32[o + 3 * i + 2] = (float)f[2][i];
+            }
+        if (out_f64)  // the reference's own result (enhancement_strategies.py:247,269-270,284-285: float64)
+            for (int i = 0; i < n; ++i) {
+                out_f64[o + 3 * i] = f[0][i];
+                out_f64[o + 3 * i + 1] = f[1][i];
+                out_f64[o + 3 * i + 2] = f[2][i];
             }
     }
 }
@@ -853,15 +860,15 @@ int launch_recover64_planar_hist(const uint8_t *d_in, const float *d_A, const do
 }
 
 int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, int apply_gamma, double gamma,
-                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src)
+                        uint8_t *d_out_u8, float *d_out_f32, hipStream_t st, const RestoreSrc *src, double *d_out_f64)
 {
     const dim3 grid(grid_for(s.npx(), 4096), s.B);
     if (src)
         UWIE_LAUNCH(k_stretch64_out<true>, grid, dim3(256), 0, st, d_planar, *src, d_pct, (int)s.npx(), apply_gamma, 1.0 / gamma,
-                    d_out_u8, d_out_f32);
+                    d_out_u8, d_out_f32, d_out_f64);
     else
         UWIE_LAUNCH(k_stretch64_out<false>, grid, dim3(256), 0, st, d_planar, RestoreSrc{}, d_pct, (int)s.npx(), apply_gamma,
-                    1.0 / gamma, d_out_u8, d_out_f32);
+                    1.0 / gamma, d_out_u8, d_out_f32, d_out_f64);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

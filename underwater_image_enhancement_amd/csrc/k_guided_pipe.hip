@@ -26,7 +26,7 @@
 // k_guided_wave.hip; a = cov/(var+eps) from the integer forms  var*(255 K^2)^2 = K^2*sum(gg) - sum(g)^2,
 // cov*255*K^4 = K^2*sum(gp) - sum(g)*sum(p), one Newton step on v_rcp_f64 (2^-23 -> 2^-46).
 // Same windows and borders as cv2.boxFilter (BORDER_REFLECT_101, anchor k/2); stated tolerance on t: 1e-11 (RING_F64),
-// 2e-10 (RING_FX32) -- tests/test_gpu_stages.py.
+// 5e-10 (RING_FX32) -- tests/test_gpu_stages.py.
 #include "common.h"
 #include "devutil.h"
 

@@ -117,6 +117,17 @@ class Device:
                                        _ptr(ws), ws.numel(), self.stream()))
         return out, outf
 
+    def enhance_u8_f64(self, frames, p: UwieParams):
+        """Dict surface: uint8 cuda tensor [B,H,W,3] -> (uint8 [B,H,W,3], float64 [B,H,W,3]): the reference's float64 image."""
+        B, H, W = self._bhw(frames)
+        assert frames.dtype == torch.uint8
+        ws = self.workspace_for(B, H, W, p)
+        out = self.empty((B, H, W, 3), torch.uint8)
+        outf = self.empty((B, H, W, 3), torch.float64)
+        check(self.lib.uwie_enhance_u8_f64(self._ctx, _ptr(frames), _ptr(out), _ptr(outf), B, H, W, ctypes.byref(p),
+                                           _ptr(ws), ws.numel(), self.stream()))
+        return out, outf
+
     def enhance_all_u8(self, frames, cast_correct: bool = True):
         """frames: uint8 cuda tensor [B,H,W,3] -> (uint8 [6,B,H,W,3] = strategies 1..6, int32 [B] cast kinds)."""
         B, H, W = self._bhw(frames)
@@ -124,7 +135,7 @@ class Device:
         p6 = (UwieParams * 6)()
         for k in range(6):
             p6[k] = self.params(_lib.SURFACE_SIX, k + 1, cast_correct=int(bool(cast_correct)))
-        ws = self.workspace_for(B, H, W, p6[0])
+        ws = self.workspace(self.lib.uwie_workspace_bytes_all(B, H, W, ctypes.cast(p6, ctypes.c_void_p)))
         out = self.empty((6, B, H, W, 3), torch.uint8)
         kind = self.empty((B,), torch.int32)
         check(self.lib.uwie_enhance_all_u8(self._ctx, _ptr(frames), _ptr(out), _ptr(kind), B, H, W,
