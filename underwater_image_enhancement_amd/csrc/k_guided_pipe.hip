@@ -78,7 +78,7 @@ struct PipeCfg {
     // in the next line (or the pad).  Only lanes >= NL read there, and their sums feed no stored output.
     static constexpr int SW = 64;
     static constexpr int s1_doubles = 6 * SW;             // P, v0 of {sum p, sum g*p, packed guide sums}
-    static constexpr int s2_doubles = 4 * SW + 8;         // P, v0 of {a, b} + pad
+    static constexpr int s2_doubles = 4 * SW + 16;        // P, v0 of {a, b} + pad (the look-ahead of the last lanes)
     // lanes >= NL own no a/b slot: the float64 ring masks them (a dummy entry would cost the fifth wavefront per CU),
     // the fixed-point ring gives them one shared dummy entry (no exec masking in the row loop)
     static constexpr int NLp(bool fx) { return fx ? NL + 1 : NL; }
@@ -671,9 +671,6 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         fix_odd[j] = sp & 1;
     }
 
-    const uint32_t a_s1 = pipe_opaque((uint32_t)ring_bytes + (uint32_t)lane * 8u);
-    const double *s1 = reinterpret_cast<const double *>(lds + a_s1);
-    const double *s2 = s1 + C::s1_doubles;
     const uint32_t a_ring = pipe_opaque((uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
 
     // what the loads return, untouched (unpacked at the point of use: an early unpack would wait for the load at once)
@@ -725,54 +722,58 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 #pragma unroll
     for (int s = 0; s < RC; ++s) *reinterpret_cast<double2 *>(lds + a_ring + (uint32_t)(s * NLp * EB)) = make_double2(0.0, 0.0);
 
-    auto window = [&](const double *ps, double P, double v1, double &o0, double &o1) {
-        double mid0 = ps[1], mid1 = ps[2];
+    // Staging, interleaved: the pair sums of TWO planes share a 16-byte entry, so a lane's look-ahead (entries l+1 .. l+M)
+    // comes in as M ds_read_b128 that serve both planes (256 B/clk in the LDS, where the ds_read2_b64 pairs of separate
+    // 8-byte lines get 128 B/clk: the kernel is LDS-time bound as much as issue bound).  Lines of 64 entries; a read past
+    // the end of a line lands in the next one and only feeds lanes whose sums are never stored.
+    //   PP1[i] = {P_p, P_gp}   VV1[i] = {p0, gp0}    PI[i] = {P_g, P_gg}  VI[i] = {g0, gg0} (uint2)   -- staged V1
+    //   PP2[i] = {P_a, P_b}    VV2[i] = {a0, b0}                                                       -- staged V2
+    const uint32_t a16 = pipe_opaque((uint32_t)ring_bytes + (uint32_t)lane * 16u);
+    const uint32_t a8 = pipe_opaque((uint32_t)ring_bytes + 2048u + (uint32_t)lane * 8u);
+    const double2 *pp1 = reinterpret_cast<const double2 *>(lds + a16), *vv1 = pp1 + SW;
+    const uint2 *pi = reinterpret_cast<const uint2 *>(lds + a8), *vi = pi + SW;
+    const double2 *pp2 = reinterpret_cast<const double2 *>(lds + a16 + 3072u), *vv2 = pp2 + SW;
+    static_assert(C::s1_doubles * 8 == 3072 && C::s2_doubles * 8 >= 2048 + 16 * (C::M + 1), "staging layout");
+    // window sums of a plane pair: o[0] = slots 2l .. 2l+K-1, o[1] = slots 2l+1 .. 2l+K (odd K)
+    auto window2 = [&](const double2 *pp, const double2 *vv, double2 P, double2 v1, double2 (&o)[2]) {
+        double2 m0 = pp[1], m1 = pp[2];
 #pragma unroll
-        for (int d = 3; d < M; d += 2) mid0 += ps[d];
+        for (int d = 3; d < M; d += 2) { const double2 t = pp[d]; m0.x += t.x; m0.y += t.y; }
 #pragma unroll
-        for (int d = 4; d < M; d += 2) mid1 += ps[d];
-        const double mid = mid0 + mid1, f0 = ps[SW + M];
-        o0 = (P + mid) + f0;
-        o1 = (v1 + mid) + ps[M];
+        for (int d = 4; d < M; d += 2) { const double2 t = pp[d]; m1.x += t.x; m1.y += t.y; }
+        const double2 f0 = vv[M], pm = pp[M];
+        const double midx = m0.x + m1.x, midy = m0.y + m1.y;
+        o[0] = make_double2((P.x + midx) + f0.x, (P.y + midy) + f0.y);
+        o[1] = make_double2((v1.x + midx) + pm.x, (v1.y + midy) + pm.y);
     };
     auto stage_v1 = [&]() {
-        double *w1 = const_cast<double *>(s1);
-        w1[0] = V1p[0] + V1p[1];
-        w1[SW] = V1p[0];
-        w1[2 * SW] = V1gp[0] + V1gp[1];
-        w1[3 * SW] = V1gp[0];
-        uint2 *wi = reinterpret_cast<uint2 *>(w1 + 4 * SW);
-        wi[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
-        wi[SW] = make_uint2(Sg[0], Sgg[0]);
+        const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
+        const_cast<double2 *>(vv1)[0] = make_double2(V1p[0], V1gp[0]);
+        const_cast<uint2 *>(pi)[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
+        const_cast<uint2 *>(vi)[0] = make_uint2(Sg[0], Sgg[0]);
     };
 
     // One step i: C(i-2) [not in the warm period], B(i-1) on ring slot S, A(i).
     auto step = [&](auto warm_tag, auto slot_tag, const In &in, uint32_t orow) {
         constexpr bool WARM = decltype(warm_tag)::value;
         constexpr int S = decltype(slot_tag)::value;
-        double *w2 = const_cast<double *>(s2);
-        const uint2 *s1i = reinterpret_cast<const uint2 *>(s1 + 4 * SW);
         char *ring_p = lds + a_ring + (uint32_t)(S * NLp * EB);
 
         // ================= read phase
-        double oa[2] = {0.0, 0.0}, ob[2] = {0.0, 0.0};
-        if constexpr (!WARM) {
-            window(s2, V2a[0] + V2a[1], V2a[1], oa[0], oa[1]);
-            window(s2 + 2 * SW, V2b[0] + V2b[1], V2b[1], ob[0], ob[1]);
-        }
-        double oP[2], oGP[2];
+        double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
+        if constexpr (!WARM) window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
+        double2 opg[2];  // {sum p, sum g*p}
+        window2(pp1, vv1, make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]), make_double2(V1p[1], V1gp[1]), opg);
         uint32_t oG[2], oGG[2];
-        window(s1, V1p[0] + V1p[1], V1p[1], oP[0], oP[1]);
-        window(s1 + 2 * SW, V1gp[0] + V1gp[1], V1gp[1], oGP[0], oGP[1]);
         {
-            const uint2 *ps = s1i;
+            const uint2 *ps = pi;
             uint2 m0 = ps[1], m1 = ps[2];
 #pragma unroll
             for (int d = 3; d < M; d += 2) { m0.x += ps[d].x; m0.y += ps[d].y; }
 #pragma unroll
             for (int d = 4; d < M; d += 2) { m1.x += ps[d].x; m1.y += ps[d].y; }
             const uint32_t midg = m0.x + m1.x, midgg = m0.y + m1.y;
-            const uint2 f0 = ps[SW + M], pm = ps[M];
+            const uint2 f0 = vi[M], pm = ps[M];
             oG[0] = Sg[0] + Sg[1] + midg + f0.x;   oGG[0] = Sgg[0] + Sgg[1] + midgg + f0.y;
             oG[1] = Sg[1] + midg + pm.x;           oGG[1] = Sgg[1] + midgg + pm.y;
         }
@@ -783,7 +784,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double gd = (double)byte_of(in.go, c);
-                const double q = fmin(fmax(fma(oa[c] * cs.kaI, gd, fma(ob[c], cs.kb, cs.b0)), 0.1), 1.0);
+                const double q = fmin(fmax(fma(oab[c].x * cs.kaI, gd, fma(oab[c].y, cs.kb, cs.b0)), 0.1), 1.0);
                 if constexpr (std::is_same<TOut, double>::value)
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q), rO, ofs_q[c], orow, 0);
                 else
@@ -797,9 +798,9 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             const uint32_t nvar = oGG[c] * (uint32_t)(K * K) - oG[c] * oG[c];  // (255 K^2)^2 var: exact
             const double D = fma((double)nvar, 1.0 / 255.0, cs.Ek);            // 255 K^4 (var + eps)
             const double gd = (double)oG[c];
-            const double ncov = fma(K2, oGP[c], -(gd * oP[c]));                // 255 K^4 cov
+            const double ncov = fma(K2, opg[c].y, -(gd * opg[c].x));           // 255 K^4 cov
             av[c] = ncov * pipe_rcp(D);
-            bv[c] = fma(av[c] * (-1.0 / 255.0), gd, oP[c]) * (1.0 / K2);
+            bv[c] = fma(av[c] * (-1.0 / 255.0), gd, opg[c].x) * (1.0 / K2);
         }
         if constexpr (EDGE) {
             double fa[2] = {av[0], av[1]}, fb[2] = {bv[0], bv[1]};
@@ -837,10 +838,8 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         // ================= write phase
         pipe_sync();
         stage_v1();
-        w2[0] = V2a[0] + V2a[1];
-        w2[SW] = V2a[0];
-        w2[2 * SW] = V2b[0] + V2b[1];
-        w2[3 * SW] = V2b[0];
+        const_cast<double2 *>(pp2)[0] = make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]);
+        const_cast<double2 *>(vv2)[0] = make_double2(V2a[0], V2b[0]);
         *reinterpret_cast<double2 *>(ring_p) = make_double2(av[0], av[1]);
         pipe_sync();
     };
