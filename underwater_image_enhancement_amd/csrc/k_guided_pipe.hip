@@ -954,7 +954,7 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
 
 // ring: 0 = float64, 1 = fixed-point int32 (requires 0.1 <= t0 <= 1: the caller's pre-clip, six_stadigy.py:174)
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
-                       int *handled, hipStream_t st)
+                       int *handled, hipStream_t st, const SideStream *side)
 {
     *handled = 0;
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || !(eps > 0.0)) return UWIE_OK;
@@ -1007,8 +1007,20 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
             // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
             if (!env_b && (long)cdiv(s.W, C::NV) * s.B * nb < 1024) goto general;
             const int border[6] = {iy0, iy1, band, 0, 0, 0};  // rows [0, iy0) and [iy1, H) of every strip
+            // the border rows are independent of the interior (disjoint outputs): on the side stream, if there is one,
+            // their short, ragged launch fills the main kernel's idle slots instead of following it
+            hipStream_t bst = st;
+            if (side) {
+                UWIE_HIP_CHECK(hipEventRecord(side->fork, st));
+                UWIE_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+                bst = side->stream;
+            }
+            UWIE_TRY_RC((launch_pipe<15, false, double>(d_gray, d_t0, s, cs, d_t, bst, border)));
             UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, st)));
-            UWIE_TRY_RC((launch_pipe<15, false, double>(d_gray, d_t0, s, cs, d_t, st, border)));
+            if (side) {
+                UWIE_HIP_CHECK(hipEventRecord(side->join, side->stream));
+                UWIE_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
+            }
             *handled = 1;
             return UWIE_OK;
         }
