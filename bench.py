@@ -36,6 +36,9 @@ KERNEL_BYTES_PER_PX = {
     "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_gradnms<true>": 1 * Q, "k_canny_gradnms<false>": (1 + 1) * Q,
     "k_canny_union": 1 * Q, "k_canny_mark": 1 * Q, "k_canny_emit": 1 * Q,
     "k_trans_init": 3 + 4, "k_guided_fast<TH>": 1 + 4 + 8, "k_guided_wave": 1 + 4 + 8,
+    # the default guided filter is two launches that split the rows of a frame (uwie_guided_plan): main() scales these by
+    # the fraction of the rows each covers
+    "k_guided_split": 1 + 4 + 8, "k_guided_pipe": 1 + 4 + 8,
     "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
     "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
     "k_sel_hist<V>": 2 * 3 * 4, "k_restore_hist_collect": 3 + 8 + 12, "k_restore_hist_lin": 3 + 8 + 12,
@@ -83,40 +86,54 @@ def synth_frames(dist, batch, H, W, device, seed):
     return torch.clamp(torch.floor(u * 256.0), 0, 255).to(torch.uint8)
 
 
-def cpu_baseline(frames_host, gpu_out_host, strategy, budget_s=25.0):
-    """Time the CPU oracle on a bounded sample -- the first frames of the timed batch, at least one, until ~budget --
-    and compare the GPU output of those frames with it (max |delta| in LSB, uint8 PSNR)."""
+def cpu_baseline(frames_host, gpu_out_host, strategy, dist):
+    """The CPU oracle (NumPy + C restatement of the reference path, one thread) on a bounded sample of the workload, as
+    BASELINE.md section 3 lays out: the median of five timings at each of 640x480, 1920x1080 and the frame size of the
+    timed batch.  At the batch's own size the five runs are its first five frames, and the GPU output of those frames is
+    compared with what the oracle returned (max |delta| in LSB, uint8 PSNR).  `value` is the rate at the batch's size."""
     import numpy as np
+    import torch
 
     from oracle import uwie_oracle as orc
 
     H, W = frames_host.shape[1:3]
     orc.enhance_u8(np.ascontiguousarray(frames_host[0, : H // 8, : W // 8]), strategy)  # warm-up (library load, tables)
-    done, t0, worst, sq, nbytes = 0, time.perf_counter(), 0, 0.0, 0
-    dt = 0.0
-    while done < len(frames_host):
+    by_size, t_all = {}, time.perf_counter()
+    for (h, w) in ((480, 640), (1080, 1920)):
+        if (h, w) == (H, W):
+            continue
+        fr = synth_frames(dist, 5, h, w, torch.device("cpu"), seed=1000 * 1).numpy()
+        ts = []
+        for i in range(5):
+            t1 = time.perf_counter()
+            orc.enhance_u8(fr[i], strategy)
+            ts.append(time.perf_counter() - t1)
+        by_size[f"{w}x{h}"] = round(h * w / 1e6 / sorted(ts)[2], 3)
+    ts, worst, sq, nbytes = [], 0, 0.0, 0
+    n = min(5, len(frames_host))
+    for i in range(n):
         t1 = time.perf_counter()
-        want = orc.enhance_u8(frames_host[done], strategy)
-        dt += time.perf_counter() - t1
-        d = np.abs(want.astype(np.int16) - gpu_out_host[done].astype(np.int16))
+        want = orc.enhance_u8(frames_host[i], strategy)
+        ts.append(time.perf_counter() - t1)
+        d = np.abs(want.astype(np.int16) - gpu_out_host[i].astype(np.int16))
         worst = max(worst, int(d.max()))
         sq += float((d.astype(np.float64) ** 2).sum())
         nbytes += d.size
-        done += 1
-        if time.perf_counter() - t0 > budget_s * 0.6:
-            break
+    by_size[f"{W}x{H}"] = round(H * W / 1e6 / sorted(ts)[len(ts) // 2], 3)
     mse = sq / nbytes
-    return {"value": round(done * H * W / 1e6 / dt, 3), "unit": "megapixels/sec", "cores": 1, "kind": "port",
-            "sample": f"{done} frame(s) of {W}x{H} (the first frames of the timed batch) through oracle.enhance_u8 "
-                      f"(NumPy + C restatement, 1 thread), {dt:.1f} s",
+    return {"value": by_size[f"{W}x{H}"], "unit": "megapixels/sec", "cores": 1, "kind": "port",
+            "sample": f"median of {n} frames of {W}x{H} (the first frames of the timed batch) through oracle.enhance_u8 "
+                      f"(NumPy + C restatement of the reference path, 1 thread); 640x480 and 1920x1080: median of 5 frames each; "
+                      f"{time.perf_counter() - t_all:.1f} s in all",
+            "megapixels_per_sec_by_size": by_size,
             "gpu_vs_oracle_max_lsb": worst, "gpu_vs_oracle_psnr_db": None if mse == 0 else round(10 * math.log10(255.0 ** 2 / mse), 2),
             "gpu_vs_oracle_bytes_compared": nbytes}
 
 
 def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
-    """HBM bytes per launch of `kernel` from the committed PMC profile of this same workload (profiles/r01_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this same workload (profiles/r02_traffic.json:
     FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes), or None when the workload differs / was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if not (os.path.exists(path) and (H, W, strategy) == (2160, 3840, 2)):
         return None
     table = json.load(open(path))["kernels"]
@@ -393,7 +410,14 @@ def main():
         ms, calls = rows[name]  # the dominant kernel, measured inside the timed region
         per_launch_ms = ms / calls
         launches_per_step = calls / args.steps
-        bytes_launch = KERNEL_BYTES_PER_PX.get(name, 0) * px_step / launches_per_step
+        cover = 1.0
+        if name in ("k_guided_split", "k_guided_pipe"):  # the two launches of the guided filter share the rows of a frame
+            import ctypes
+
+            r0, rows = ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(dev.lib.uwie_guided_plan(B, H, W, int(p.gf_ksize), ctypes.byref(r0), ctypes.byref(rows)))
+            cover = rows.value / H if name == "k_guided_split" else 1.0 - rows.value / H
+        bytes_launch = KERNEL_BYTES_PER_PX.get(name, 0) * cover * px_step / launches_per_step
         achieved = bytes_launch / (per_launch_ms * 1e-3) / 1e9
         kernel_ms = sum(v[0] for v in table.values())  # all kernels, from the recorded warm-up step
         result = {
@@ -408,7 +432,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": measured_traffic(name, H, W, B, args.strategy, launches_per_step), "kernel": name,
                          "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_launch": bytes_launch, "rows_covered_frac": round(cover, 4),
                          "kernel_share_of_step": round(ms / args.steps / (elapsed / args.steps * 1e3), 4),
                          "pipeline_achieved": round(PIPELINE_BYTES_PER_PX * px_step * args.steps / elapsed / 1e9, 2),
                          "pipeline_frac": round(PIPELINE_BYTES_PER_PX * px_step * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
@@ -418,7 +442,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             n_cmp = min(B, 8)
-            result["cpu_baseline"] = cpu_baseline(frames[:n_cmp].cpu().numpy(), out[:n_cmp].cpu().numpy(), args.strategy)
+            result["cpu_baseline"] = cpu_baseline(frames[:n_cmp].cpu().numpy(), out[:n_cmp].cpu().numpy(), args.strategy, args.dist)
         if world == 1 and not args.no_extras:
             result["extras"] = extras(dev, args, torch, _lib)
         if os.environ.get("UWIE_BENCH_KERNELS"):

@@ -213,6 +213,11 @@ int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int b
 int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, int batch, int H, int W, int ksize,
                        double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Which rows of a frame the default float64 guided filter (gf_exact = 0, inter_dtype = F64) hands to its main kernel
+ * (k_guided_split: rows [*split_row0, *split_row0 + *split_rows)); the rows around them go to the general kernel in a
+ * second launch.  0 rows = the general kernel alone.  For benchmarks that price each kernel by the pixels it covers. */
+int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *split_rows);
+
 /* restore_image (S6:183-188): float32 [batch][H][W][3]. */
 int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t,
                  int batch, int H, int W, float *d_out_f32, void *stream);

@@ -250,6 +250,38 @@ def test_parameter_checks_and_merged_fan_out_workspace(uw, orc):
     assert rc != 0
 
 
+def test_config2_4k_batch64(uw, orc):
+    """BASELINE.json configs[2] at its full size: 64 frames of 3840x2160 in one call (the split-ring guided kernel, the
+    wide quadtree levels and every other stage at the launch shapes bench.py times).  Size-independent properties: the
+    batch equals the single-frame calls on sampled frames (first, last, a greenish, a bluish and a noise frame), one frame
+    equals the oracle, and the workspace the library asks for is enough (the call would fail otherwise)."""
+    import torch
+
+    dev = uw.get_device()
+    B, H, W = 64, 2160, 3840
+    g = torch.Generator(device=dev.torch_device).manual_seed(642)
+    yy = torch.arange(H, device=dev.torch_device, dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device=dev.torch_device, dtype=torch.float32)[None, :]
+    frames = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev.torch_device)
+    for b in range(B):
+        ph = torch.rand(4, generator=g, device=dev.torch_device) * 6.283
+        field = 0.55 + 0.125 * (torch.sin(xx / (W / 9.0) + ph[0]) * torch.cos(yy / (H / 7.0) + ph[1])
+                                + 0.5 * torch.sin((xx + 2 * yy) / (W / 5.0) + ph[2]))
+        gains = (0.45, 0.85, 0.80) if b % 2 == 0 else (0.45, 0.75, 0.90)
+        for c in range(3):
+            ch = field * gains[c] + torch.randn((H, W), generator=g, device=dev.torch_device) * 0.02
+            frames[b, :, :, c] = torch.clamp(torch.floor(ch * 255.0), 0, 255).to(torch.uint8)
+    frames[37] = torch.randint(0, 256, (H, W, 3), generator=g, device=dev.torch_device, dtype=torch.uint8)
+    out = uw.enhance(frames)
+    assert out.shape == frames.shape and out.dtype == torch.uint8
+    for b in (0, 1, 37, 62, 63):
+        assert torch.equal(out[b], uw.enhance(frames[b:b + 1])[0]), f"frame {b} of the batch differs from its single call"
+    u8 = frames[2].cpu().numpy()
+    assert check_u8(out[2].cpu().numpy(), orc.enhance_u8(u8, 2), "frame 2 of the 4K x 64 batch") == 0
+    del frames, out
+    torch.cuda.empty_cache()
+
+
 def test_config2_4k_frame_matches_oracle_and_batch_is_invariant(uw, orc):
     """BASELINE.json configs[2] frame size (3840x2160): one frame against the oracle, then the size-independent
     properties on a batch: batch == singles, frame order does not matter, a 'normal' cast is the identity."""

@@ -65,6 +65,7 @@ SIGNATURES = {
     "uwie_params_init": [_PP, _I, _I],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
     "uwie_workspace_bytes_all": [_I, _I, _I, _VP],
+    "uwie_guided_plan": [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "uwie_enhance_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_u8_f64": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_all_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP],

@@ -724,6 +724,17 @@ int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, 
     return launch_guided(d_gray, d_t0, s, ksize, eps, d_t, d_workspace, (hipStream_t)stream);
 }
 
+int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *split_rows)
+{
+    UWIE_REQUIRE(split_row0 && split_rows, "guided_plan: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    int iy0 = 0, band = 0, nb = 0;
+    const bool split = guided_split_plan(Shape{batch, H, W}, ksize, &iy0, &band, &nb);
+    *split_row0 = split ? iy0 : 0;
+    *split_rows = split ? band * nb : 0;
+    return UWIE_OK;
+}
+
 int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t,
                  int batch, int H, int W, float *d_out_f32, void *stream)
 {

@@ -952,7 +952,35 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
 
 }  // namespace
 
-// ring: 0 = float64, 1 = fixed-point int32 (requires 0.1 <= t0 <= 1: the caller's pre-clip, six_stadigy.py:174)
+// Rows [*iy0, *iy0 + *nb * *band) go to k_guided_split (float64 ring, k = 15, an even W, a job large enough to fill the
+// chip with long bands), the rest to the general kernel; false = the general kernel alone.
+bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb)
+{
+    const char *env_split = getenv("UWIE_GF_SPLIT");
+    if (k != 15 || (s.W & 1) || (env_split && atoi(env_split) == 0)) return false;
+    if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || s.npx() >= ((size_t)1 << 27)) return false;
+    using C = PipeCfg<15>;
+    *iy0 = 2 * C::a;                                            // first band: raw rows from y - 2a >= 0
+    const int periods = (s.H - C::K_ - 1 - *iy0) / C::RC;       // last band: raw rows up to y_hi + K <= H - 1
+    if (periods < 4) return false;
+    const long strips = (long)cdiv(s.W, C::NV) * s.B;
+    const char *env_b = getenv("UWIE_GF_BANDS");
+    int n;
+    if (env_b) n = atoi(env_b);
+    else {
+        // ~8 wavefronts per resident slot (256 CUs x 8) even out the tail; a band costs one extra ring period
+        n = (int)cdiv((size_t)(8L * 2048), (size_t)strips);
+        n = std::min(n, std::max(1, periods / 12));  // ... but at least 12 periods (180 rows) long
+    }
+    n = std::max(1, std::min(n, periods));
+    *band = C::RC * (periods / n);
+    *nb = n;
+    // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
+    return env_b || strips * n >= 1024;
+}
+
+// ring: 0 = float64 (split ring where guided_split_plan takes the job), 1 = fixed-point int32 (requires 0.1 <= t0 <= 1:
+// the caller's pre-clip, six_stadigy.py:174)
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
                        int *handled, hipStream_t st, const SideStream *side)
 {
@@ -987,28 +1015,13 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
     }
     // float64, k = 15: the split-ring kernel takes the rows whose windows touch neither the top nor the bottom image
     // border (every strip), the general kernel the rows above and below.  UWIE_GF_SPLIT=0 (read per call) keeps one general launch.
-    const char *env_split = getenv("UWIE_GF_SPLIT");
-    if (ring == 0 && k == 15 && !(s.W & 1) && !(env_split && atoi(env_split) == 0)) {
-        using C = PipeCfg<15>;
-        const int iy0 = 2 * C::a;                                            // first band: raw rows from y - 2a >= 0
-        const int periods = (s.H - C::K_ - 1 - iy0) / C::RC;                 // last band: raw rows up to y_hi + K <= H - 1
-        if (periods >= 4) {
-            int nb;
-            const char *env_b = getenv("UWIE_GF_BANDS");
-            if (env_b) nb = atoi(env_b);
-            else {
-                // ~8 wavefronts per resident slot (256 CUs x 8) even out the tail; a band costs one extra ring period
-                const long strips = (long)cdiv(s.W, C::NV) * s.B;
-                nb = (int)cdiv((size_t)(8L * 2048), (size_t)strips);
-                nb = std::min(nb, std::max(1, periods / 12));  // ... but at least 12 periods (180 rows) long
-            }
-            nb = std::max(1, std::min(nb, periods));
-            const int band = C::RC * (periods / nb), iy1 = iy0 + nb * band;
-            // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
-            if (!env_b && (long)cdiv(s.W, C::NV) * s.B * nb < 1024) goto general;
+    if (ring == 0) {
+        int iy0, band, nb;
+        if (guided_split_plan(s, k, &iy0, &band, &nb)) {
+            const int iy1 = iy0 + nb * band;
             const int border[6] = {iy0, iy1, band, 0, 0, 0};  // rows [0, iy0) and [iy1, H) of every strip
             // the border rows are independent of the interior (disjoint outputs): on the side stream, if there is one,
-            // their short, ragged launch fills the main kernel's idle slots instead of following it
+            // their short, ragged launch runs beside the main kernel instead of after it
             hipStream_t bst = st;
             if (side) {
                 UWIE_HIP_CHECK(hipEventRecord(side->fork, st));
@@ -1025,7 +1038,6 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
             return UWIE_OK;
         }
     }
-general:
     int rc;
 #define UWIE_PIPE_CASE(KK)                                                                                   \
     case KK:                                                                                                 \
