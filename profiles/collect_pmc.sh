@@ -15,4 +15,5 @@ mkdir -p $OUT
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+run req TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum
 ls -R $OUT | head -30

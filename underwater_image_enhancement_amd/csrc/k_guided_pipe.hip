@@ -618,6 +618,44 @@ struct RegRing<0> {
 template <int N>
 using IC = std::integral_constant<int, N>;
 
+// The last RC raw rows of a lane's two slots (transmission as float32 bits, the two guide bytes packed), in registers: the
+// row that leaves the first box filter's window is the row that entered RC steps earlier, so it is never re-read from
+// memory (those re-reads missed L2 and doubled the kernel's HBM traffic).
+template <int N>
+struct RawRing {
+    uint32_t t0, t1, g;
+    RawRing<N - 1> rest;
+    template <int S>
+    __device__ __forceinline__ void swap_at(uint32_t &a0, uint32_t &a1, uint32_t &gg)
+    {
+        if constexpr (S == 0) {
+            const uint32_t o0 = t0, o1 = t1;
+            t0 = a0; t1 = a1;
+            a0 = o0; a1 = o1;
+#if !defined(SPLIT_RAW_G) || SPLIT_RAW_G
+            const uint32_t og = g;
+            g = gg;
+            gg = og;
+#endif
+        } else rest.template swap_at<S - 1>(a0, a1, gg);
+    }
+    template <int S>
+    __device__ __forceinline__ void set_at(uint32_t a0, uint32_t a1, uint32_t gg)
+    {
+        if constexpr (S == 0) {
+            t0 = a0; t1 = a1;
+#if !defined(SPLIT_RAW_G) || SPLIT_RAW_G
+            g = gg;
+#endif
+        } else rest.template set_at<S - 1>(a0, a1, gg);
+    }
+};
+template <>
+struct RawRing<0> {
+    template <int S> __device__ __forceinline__ void swap_at(uint32_t &, uint32_t &, uint32_t &) {}
+    template <int S> __device__ __forceinline__ void set_at(uint32_t, uint32_t, uint32_t) {}
+};
+
 struct SplitGeom {
     int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
 };
@@ -674,28 +712,35 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     const uint32_t a_ring = pipe_opaque((uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
 
     // what the loads return, untouched (unpacked at the point of use: an early unpack would wait for the load at once)
+#ifndef SPLIT_RAW_G
+#define SPLIT_RAW_G 0  // 1: the guide bytes of the last RC rows ride in the register ring too (3.13 ms at 4K x 64: register pressure); 0: the leaving row's two bytes are re-read (3.03 ms)
+#endif
     struct In {
-        uint32_t te[2], tl[2];
-        uint32_t ge[2], gl[2], go[2];  // !EDGE: [0] holds both bytes
+        uint32_t te[2];         // entering raw row: float bits of the two slots
+        uint32_t ge[2], go[2];  // its guide bytes / the guide bytes of the output row; !EDGE: [0] holds both bytes
+        uint32_t gl[2];         // (SPLIT_RAW_G == 0) guide bytes of the leaving row
     };
     auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
-    auto load_rows = [&](uint32_t oe_t, uint32_t ol_t, uint32_t oe_g, uint32_t ol_g, uint32_t oo_g, In &in) {
+    auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t oo_g, In &in) {
+#if !SPLIT_RAW_G
+        const uint32_t ol_g = oe_g - (uint32_t)RC * pitch_g;
+        if constexpr (!EDGE) in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
+        else {
+            in.gl[0] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[0], ol_g, 0);
+            in.gl[1] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[1], ol_g, 0);
+        }
+#endif
         if constexpr (!EDGE) {
             const u32x2 te = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], oe_t, 0);
-            const u32x2 tl = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], ol_t, 0);
             in.ge[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], oe_g, 0);
-            in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
             in.go[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_o[0], oo_g, 0);
             in.te[0] = te.x; in.te[1] = te.y;
-            in.tl[0] = tl.x; in.tl[1] = tl.y;
-            in.ge[1] = in.gl[1] = in.go[1] = 0;
+            in.ge[1] = in.go[1] = 0;
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 in.te[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], oe_t, 0);
-                in.tl[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], ol_t, 0);
                 in.ge[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], oe_g, 0);
-                in.gl[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], ol_g, 0);
                 in.go[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_o[j], oo_g, 0);
             }
         }
@@ -705,18 +750,25 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     double V1p[2] = {0.0, 0.0}, V1gp[2] = {0.0, 0.0};
     uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};
     double V2a[2] = {0.0, 0.0}, V2b[2] = {0.0, 0.0};
-    for (int j = 0; j < K; ++j) {
-        const uint32_t row = (uint32_t)(r_lo - a + j);
+    static_assert(K == RC, "odd window: the raw window of an a/b row is one ring period");
+    RawRing<RC> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
+    auto prologue_row = [&](auto j_tag) {
+        constexpr int J = decltype(j_tag)::value;
+        const uint32_t row = (uint32_t)(r_lo - a + J);
+        uint32_t tb[2], gq[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const uint32_t gq = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[c], row * pitch_g, 0);
-            const double p = (double)__uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0));
-            Sg[c] += gq;
-            Sgg[c] += gq * gq;
+            gq[c] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[c], row * pitch_g, 0);
+            tb[c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0);
+            const double p = (double)__uint_as_float(tb[c]);
+            Sg[c] += gq[c];
+            Sgg[c] += gq[c] * gq[c];
             V1p[c] += p;
-            V1gp[c] += (double)gq * p;
+            V1gp[c] += (double)gq[c] * p;
         }
-    }
+        raw.template set_at<J>(tb[0], tb[1], gq[0] | (gq[1] << 8));
+    };
+    [&]<int... J>(std::integer_sequence<int, J...>) { (prologue_row(IC<J>{}), ...); }(std::make_integer_sequence<int, RC>{});
     RegRing<RC> rb;
     rb.clear();
 #pragma unroll
@@ -824,11 +876,16 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         rb.template swap_at<S>(lb0, lb1);  // registers: new b in, b of the leaving row out
         V2a[0] += av[0] - la.x; V2a[1] += av[1] - la.y;
         V2b[0] += bv[0] - lb0;  V2b[1] += bv[1] - lb1;
-        // A: V1 += raw(entering) - raw(leaving)
+        // A: V1 += raw(entering) - raw(leaving); the entering row takes the leaving row's place in the register ring
+        uint32_t lt[2] = {in.te[0], in.te[1]}, lg = EDGE ? (in.ge[0] | (in.ge[1] << 8)) : in.ge[0];
+        raw.template swap_at<S>(lt[0], lt[1], lg);
+#if !SPLIT_RAW_G
+        lg = EDGE ? (in.gl[0] | (in.gl[1] << 8)) : in.gl[0];
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double pe = (double)__uint_as_float(in.te[c]), pl = (double)__uint_as_float(in.tl[c]);
-            const uint32_t ge = byte_of(in.ge, c), gl = byte_of(in.gl, c);
+            const double pe = (double)__uint_as_float(in.te[c]), pl = (double)__uint_as_float(lt[c]);
+            const uint32_t ge = byte_of(in.ge, c), gl = c == 0 ? (lg & 255u) : (lg >> 8);
             Sg[c] += ge - gl;
             Sgg[c] += ge * ge - gl * gl;
             V1p[c] += pe - pl;
@@ -849,20 +906,19 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     stage_v1();
     pipe_sync();
     int i = r_lo + 1;
-    uint32_t oe_t = (uint32_t)(i + Lb) * pitch_t, ol_t = (uint32_t)(i - 1 - a) * pitch_t;
-    uint32_t oe_g = (uint32_t)(i + Lb) * pitch_g, ol_g = (uint32_t)(i - 1 - a) * pitch_g;
+    uint32_t oe_t = (uint32_t)(i + Lb) * pitch_t, oe_g = (uint32_t)(i + Lb) * pitch_g;
     uint32_t oo_g = (uint32_t)max(i - 2 - a, 0) * pitch_g;  // (unused before the first normal step: i - 2 - a = y_lo there)
-    auto advance_loads = [&]() { oe_t += pitch_t; ol_t += pitch_t; oe_g += pitch_g; ol_g += pitch_g; };
+    auto advance_loads = [&]() { oe_t += pitch_t; oe_g += pitch_g; };
     In b0, b1, b2;
-    load_rows(oe_t, ol_t, oe_g, ol_g, oo_g, b0);
+    load_rows(oe_t, oe_g, oo_g, b0);
     advance_loads();
-    load_rows(oe_t, ol_t, oe_g, ol_g, oo_g, b1);
+    load_rows(oe_t, oe_g, oo_g, b1);
     advance_loads();
     // guide rows of C: step i stores row i-2-a; its byte comes with the loads issued two steps earlier.  The first normal
     // step is i = r_lo+RC+1 (row y_lo), loaded at warm step n = RC-2.
     uint32_t orow = (uint32_t)y_lo * pitch_o;
     auto one = [&](auto warm_tag, auto slot_tag, In &fill, const In &use, uint32_t guide_row_ofs) {
-        load_rows(oe_t, ol_t, oe_g, ol_g, guide_row_ofs, fill);
+        load_rows(oe_t, oe_g, guide_row_ofs, fill);
         step(warm_tag, slot_tag, use, orow);
         advance_loads();
         if constexpr (!decltype(warm_tag)::value) orow += pitch_o;
