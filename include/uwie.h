@@ -64,7 +64,7 @@ typedef struct uwie_params {
                               color_correction for this kind (caller ran detect_image_type itself)  */
     int32_t gray_shift;    /* RGB2GRAY fixed point: 15 (OpenCV 4.x, default) or 14               */
     int32_t min_size;      /* quadtree leaf size (S6:49, ES:77): 1                               */
-    float omega;           /* S6:173 / ES:225                                                    */
+    double omega;          /* S6:173 / ES:225 (a Python float there: float32 arithmetic rounds it, float64 keeps it) */
     int32_t gf_ksize;      /* guided-filter box WIDTH `r` (S6:31, ES:31)                         */
     double gf_eps;         /* S6: 0.5/0.5/0.1 (:234,245,255); ES: always 0.001 (:209)            */
     double L_low, L_high;  /* percentile stretch bounds in percent (S6:191, ES:252)              */
@@ -130,6 +130,26 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
  * own quantisation of the same values.  UWIE_SURFACE_DICT only; same workspace as uwie_enhance_u8. */
 int uwie_enhance_u8_f64(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, double *d_out_f64, int batch, int H, int W,
                         const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The same strategies on GENERAL float images: the reference's functions take "float HxWx3 in [0, 1]" (S6:230-285,
+ * ES:477-508) and its own harnesses feed np.random.rand (ES:516, example_usage.py:27,44,112).  uwie_enhance_u8 starts from
+ * the u8 frame a float image was made of (the fast path: every kernel exploits that a pixel value is a function of its
+ * byte); an image that is NOT u8-derived goes through these entry points: the same arithmetic with the pixel values read
+ * from the float image, then the materialised-image stage kernels.  Written for parity, not speed.
+ *   uwie_enhance_f32: float32 [batch][H][W][3] in.  SIX surface: strategy1..6(img) [with detect_image_type /
+ *     color_correction first when cast_correct or forced_cast say so]; float32 image to d_out_f32, its (y*255).astype(u8)
+ *     to d_out_u8.  DICT surface: apply_strategy body; the reference's float64 image to d_out_f64 (and/or float32 / u8).
+ *   uwie_enhance_f64: float64 in, DICT surface only (six_stadigy.py works on float32 frames, S6:406).
+ *   uwie_workspace_bytes_float: scratch bytes of either (elem_bytes = 4 or 8).
+ *   uwie_cast_classify_f32: detect_image_type (S6:292-302) on a general float32 image. */
+size_t uwie_workspace_bytes_float(int batch, int H, int W, const uwie_params *p, int elem_bytes);
+int uwie_enhance_f32(uwie_ctx *ctx, const float *d_img, uint8_t *d_out_u8, float *d_out_f32, double *d_out_f64, int batch, int H, int W,
+                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+int uwie_enhance_f64(uwie_ctx *ctx, const double *d_img, uint8_t *d_out_u8, double *d_out_f64, int batch, int H, int W,
+                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream);
+int uwie_cast_classify_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, int W, int32_t *d_kind, float *d_mean_rgb, void *stream);
+/* color_correction (S6:305-323) of a general float32 image: d_kind[b] = UWIE_CAST_* per image (NORMAL copies). */
+int uwie_color_correct_f32(uwie_ctx *ctx, const float *d_img, const int32_t *d_kind, float *d_out, int batch, int H, int W, void *stream);
 
 /* Scratch bytes uwie_enhance_all_u8 needs for these six parameter sets (NULL = the defaults): one layout sized for the
  * most demanding of them (exact-order guided filter planes, widest CLAHE tile grid). */

@@ -87,8 +87,8 @@ def test_float_surface_mirrors_reference_api(uw, orc):
     y = uw.SixStrategies.strategy2_medium_dehazing(xc)
     want = orc.SixStrategyOracle.strategy(2, orc.correct_cast(x, kind))
     assert y.dtype == np.float32 and np.array_equal(y, want)
-    with pytest.raises(ValueError):
-        uw.SixStrategies.strategy2_medium_dehazing(rng.random((8, 8, 3)).astype(np.float32))
+    r = rng.random((40, 44, 3)).astype(np.float32)  # not u8-derived: the general float path (see the test further down)
+    assert np.abs(uw.SixStrategies.strategy2_medium_dehazing(r) - orc.SixStrategyOracle.strategy(2, r)).max() <= 2e-7
     with pytest.raises(ValueError):
         uw.EnhancementStrategies.apply_strategy(x, "no_such_strategy", {})
 
@@ -174,12 +174,11 @@ def test_dict_surface_error_behaviour(uw, orc):
         uw.EnhancementStrategies.apply_strategy(x, "weak_dehazing", {})  # commented out in the reference (ES:494-496)
     # ES:503-508 swallows failures INSIDE a strategy and returns the input (here: a window wider than the frame)
     assert uw.EnhancementStrategies.apply_strategy(x, "strong_dehazing", {"guided_radius": 4000}) is x
-    # ... but an image this build has no device path for (not u8-derived) is refused, never passed through as a success
-    bad = rng.random((16, 16, 3)).astype(np.float32)
+    # ... but an image this build has no device path for is refused, never passed through as a success
     with pytest.raises(uw.UnsupportedInputError):
-        uw.EnhancementStrategies.apply_strategy(bad, "strong_dehazing", {})
+        uw.EnhancementStrategies.apply_strategy((x * 255).astype(np.int32), "strong_dehazing", {})
     with pytest.raises(uw.UnsupportedInputError):
-        uw.SixStrategies.strategy2_medium_dehazing(bad)
+        uw.SixStrategies.strategy2_medium_dehazing(rng.random((16, 16, 3)))  # float64 on the float32 surface
 
 
 @pytest.mark.parametrize("strategy", [1, 2, 3])
@@ -421,3 +420,49 @@ def test_select_paths_agree(uw, orc, monkeypatch):
     monkeypatch.delenv("UWIE_RESTORE_STORE")
     batch = np.stack([noisy[:120, :200], flatish[:120, :200], noisy[30:150, 10:210]])
     assert np.array_equal(uw.enhance(batch, strategy=2), np.stack([uw.enhance(f, strategy=2) for f in batch]))
+
+
+# ------------------------------------------------------------------ general (not u8-derived) float images
+def test_general_float_images_on_both_surfaces(uw, orc):
+    """The reference's functions take any float image in [0, 1]; its own harnesses feed np.random.rand
+    (enhancement_strategies.py:516,526; example_usage.py:27-31,44-48,112).  Not u8-derived images take the general float
+    path (uwie_enhance_f32 / _f64): float64 and float32 through the five dict strategies, float32 through the six
+    six_stadigy strategies, against the oracle.  Without pow and with the exact-order guided filter every float is
+    reproduced bit for bit; the fused guided filter (default on float32 images) is within its 1e-11 on t, and pow within a
+    few ulp between libraries."""
+    rng = np.random.default_rng(20240516)
+    x64 = rng.random((256, 256, 3))
+    x32 = rng.random((96, 131, 3)).astype(np.float32)
+    hazy = (rng.random((120, 88, 3)) * 0.7 + 0.15).astype(np.float32)  # example_usage.py:112
+    ES = orc.DictStrategyOracle
+    for name in ("strong_dehazing", "medium_dehazing", "light_enhancement", "clahe_enhancement", "histogram_equalization"):
+        for params in (orc.CONFIG_STRATEGIES[name], {}):
+            for x in (x64, x32, hazy):
+                want = ES.run(x, name, params)
+                got = uw.EnhancementStrategies.apply_strategy(x, name, params)
+                assert got.dtype == np.float64 and got.shape == want.shape, (name, x.dtype)
+                tol = 1e-9 if (params.get("apply_gamma", False) or (x.dtype == np.float32 and "dehaz" in name or name == "light_enhancement")) else 0.0
+                err = np.abs(got - want).max()
+                assert err <= tol, (name, params, x.dtype, err)
+                dq = np.abs((got * 255).astype(np.uint8).astype(int) - (want * 255).astype(np.uint8).astype(int))
+                assert dq.max() <= (1 if tol else 0), (name, x.dtype, int(dq.max()))
+    S6 = orc.SixStrategyOracle
+    fns = (uw.SixStrategies.strategy1_strong_dehazing, uw.SixStrategies.strategy2_medium_dehazing,
+           uw.SixStrategies.strategy3_light_dehazing, uw.SixStrategies.strategy4_clahe_enhancement,
+           uw.SixStrategies.strategy5_white_balance, uw.SixStrategies.strategy6_histogram_eq)
+    for k, fn in enumerate(fns, start=1):
+        for x in (x32, hazy):
+            want = S6.strategy(k, x)
+            got = fn(x)
+            assert got.dtype == np.float32 and got.shape == want.shape
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 2e-7, (k, np.abs(got - want).max())
+            dq = np.abs((got * 255).astype(np.uint8).astype(int) - (want * 255).astype(np.uint8).astype(int))
+            assert dq.max() <= 1, (k, int(dq.max()))
+    # cast detection / correction on a general float image
+    g = x32.copy()
+    g[:, :, 1] = np.clip(g[:, :, 1] + 0.2, 0, 1)
+    assert uw.detect_image_type(g) == orc.classify_cast(g) == "greenish"
+    assert uw.detect_image_type(x32) == orc.classify_cast(x32)
+    assert np.array_equal(uw.color_correction(g, "greenish"), orc.correct_cast(g, "greenish"))
+    with pytest.raises(uw.UnsupportedInputError):
+        uw.SixStrategies.strategy2_medium_dehazing(x64)  # six_stadigy.py works on float32 frames

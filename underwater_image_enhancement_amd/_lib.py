@@ -34,7 +34,7 @@ class UwieParams(ctypes.Structure):
         ("forced_cast", ctypes.c_int32),
         ("gray_shift", ctypes.c_int32),
         ("min_size", ctypes.c_int32),
-        ("omega", ctypes.c_float),
+        ("omega", ctypes.c_double),
         ("gf_ksize", ctypes.c_int32),
         ("gf_eps", ctypes.c_double),
         ("L_low", ctypes.c_double),
@@ -65,6 +65,11 @@ SIGNATURES = {
     "uwie_params_init": [_PP, _I, _I],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
     "uwie_workspace_bytes_all": [_I, _I, _I, _VP],
+    "uwie_workspace_bytes_float": [_I, _I, _I, _PP, _I],
+    "uwie_enhance_f32": [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
+    "uwie_enhance_f64": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
+    "uwie_cast_classify_f32": [_VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    "uwie_color_correct_f32": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP],
     "uwie_guided_plan": [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "uwie_enhance_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_u8_f64": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
@@ -96,6 +101,7 @@ _RESTYPES = {
     "uwie_destroy": None,
     "uwie_workspace_bytes": ctypes.c_size_t,
     "uwie_workspace_bytes_all": ctypes.c_size_t,
+    "uwie_workspace_bytes_float": ctypes.c_size_t,
 }
 
 _lib = None

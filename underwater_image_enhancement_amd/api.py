@@ -9,11 +9,15 @@ Reference surfaces mirrored here (same names, argument meaning and error behavio
   ``color_correction``                           -- ``six_stadigy.py:230-285,292-323``;
 * ``EnhancementStrategies.apply_strategy(img, name, params)`` -- ``enhancement_strategies.py:477-508``.
 
-Float images handed to these functions must be u8-derived (``u8.astype(float32)/255`` possibly followed by
-``color_correction``), which is what the reference's pipelines pass (``six_stadigy.py:406``, ``main.py:108``): the
-device path starts from the u8 frame.  Anything else raises ``UnsupportedInputError`` -- also from
-``apply_strategy``, whose swallow-and-return-the-input convention (ES:503-508) is for failures INSIDE a strategy:
-an input this build cannot process is never reported as a successful pass-through.
+Float images: a u8-derived image (``u8.astype(float32)/255`` possibly followed by ``color_correction``), which is what the
+reference's pipelines pass (``six_stadigy.py:406``, ``main.py:108``), is recognised and takes the fast path that starts
+from the u8 frame.  Any other float image in ``[0, 1]`` -- the reference's own harness inputs are ``np.random.rand``
+(``enhancement_strategies.py:516``, ``example_usage.py:27,44,112``) -- takes the general float path
+(``uwie_enhance_f32`` / ``uwie_enhance_f64``: same arithmetic, pixel values read from the float image, unfused):
+float32 on both surfaces, float64 on the dict surface.  What is left raises ``UnsupportedInputError`` (float64 images on
+the six_stadigy surface, whose functions are written for float32 frames; other dtypes) -- also from ``apply_strategy``,
+whose swallow-and-return-the-input convention (ES:503-508) is for failures INSIDE a strategy: an input this build cannot
+process is never reported as a successful pass-through.
 """
 from __future__ import annotations
 
@@ -240,10 +244,31 @@ def _recover_u8(img):
     raise UnsupportedInputError("float image is not u8-derived (u8/255, optionally colour-corrected): unsupported input")
 
 
+def _float_kind(img):
+    """'u8' for a u8 frame, 'derived' for a u8-derived float image, else the dtype name of a general float image."""
+    x = np.asarray(img)
+    if x.dtype == np.uint8:
+        return "u8"
+    try:
+        _recover_u8(x)
+        return "derived"
+    except UnsupportedInputError:
+        if x.dtype in (np.float32, np.float64):
+            return x.dtype.name
+        raise
+
+
 def detect_image_type(img, device: int | None = None) -> str:
-    """six_stadigy.py:292-302 on a u8-derived float image (or a u8 frame)."""
+    """six_stadigy.py:292-302 on a float image (u8-derived: from its u8 frame; general float32: sequential mean on the
+    device) or a u8 frame."""
     dev = get_device(device)
-    u8 = img if np.asarray(img).dtype == np.uint8 else _recover_u8(img)[0]
+    what = _float_kind(img)
+    if what == "float32":
+        kind, _ = dev.cast_classify_f32(dev.tensor(np.ascontiguousarray(img)[None]))
+        return _lib.CAST_KINDS[int(kind[0])]
+    if what == "float64":
+        raise UnsupportedInputError("detect_image_type: general float64 images are not supported (six_stadigy.py works on float32)")
+    u8 = img if what == "u8" else _recover_u8(img)[0]
     kind, _ = dev.cast_classify(dev.tensor(u8[None]))
     return _lib.CAST_KINDS[int(kind[0])]
 
@@ -253,6 +278,9 @@ def color_correction(img, image_type: str, device: int | None = None):
     if image_type not in ("greenish", "bluish"):
         return img
     dev = get_device(device)
+    if _float_kind(img) == "float32":  # general float image
+        k = torch.tensor([_lib.CAST_KINDS.index(image_type)], dtype=torch.int32, device=dev.torch_device)
+        return dev.color_correct_f32(dev.tensor(np.ascontiguousarray(img)[None]), k)[0].cpu().numpy()
     u8, kind = _recover_u8(img)
     if kind != "normal":
         raise ValueError("image is already colour-corrected")
@@ -268,6 +296,13 @@ class SixStrategies:
     @classmethod
     def _run(cls, number, img):
         dev = get_device(cls.device)
+        what = _float_kind(img)
+        if what == "float32":  # general float image: strategyN(img) as it stands (no cast detection inside, S6:230-285)
+            p = dev.params(_lib.SURFACE_SIX, number, cast_correct=0, forced_cast=-1)
+            return dev.enhance_float(dev.tensor(np.ascontiguousarray(img)[None]), p)[1][0].cpu().numpy()
+        if what == "float64":
+            raise UnsupportedInputError("six_stadigy strategies take float32 images (six_stadigy.py:406); a general float64 image "
+                                        "is only supported on the dict surface (EnhancementStrategies.apply_strategy)")
         u8, kind = _recover_u8(img)
         # a colour-corrected input is replayed on the device from its u8 frame through a forced cast kind
         p = dev.params(_lib.SURFACE_SIX, number, cast_correct=0, forced_cast=_lib.CAST_KINDS.index(kind) or -1)
@@ -322,9 +357,19 @@ class EnhancementStrategies:
     @classmethod
     def _run(cls, img, name, params):
         dev = get_device(cls.device)
-        u8, kind = _recover_u8(img)
-        if kind != "normal":
-            raise ValueError("colour-corrected input is not supported on the dict surface")
+        x = np.asarray(img)
+        if x.dtype not in (np.float32, np.float64):
+            raise UnsupportedInputError(f"apply_strategy takes float32 / float64 images in [0, 1], got {x.dtype}")
+        if x.ndim != 3 or x.shape[2] != 3 or x.size == 0:
+            raise ValueError(f"expected a non-empty HxWx3 image, got {x.shape}")
+        u8 = None
+        if x.dtype == np.float32:  # main.py:108 hands over u8.astype(float32)/255: the fast path from the u8 frame
+            try:
+                cand, kind = _recover_u8(x)
+                if kind == "normal":
+                    u8 = cand
+            except UnsupportedInputError:
+                pass
         over = {}
         for key, field in (("omega", "omega"), ("guided_radius", "gf_ksize"), ("L_low", "L_low"), ("L_high", "L_high"),
                            ("clip_limit", "clip_limit"), ("gamma", "gamma")):
@@ -336,5 +381,7 @@ class EnhancementStrategies:
         p = dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], **over)
         # float64 like the reference (ES:247,307,345): a caller's (enhanced * 255).astype(np.uint8) (main.py:155) then
         # truncates the same values as with the reference
-        _, outf = dev.enhance_u8_f64(dev.tensor(u8[None]), p)
-        return outf[0].cpu().numpy()
+        if u8 is not None:
+            return dev.enhance_u8_f64(dev.tensor(u8[None]), p)[1][0].cpu().numpy()
+        # any other float32 / float64 image (the reference's harness inputs are np.random.rand): general float path
+        return dev.enhance_float(dev.tensor(np.ascontiguousarray(x)[None]), p)[1][0].cpu().numpy()

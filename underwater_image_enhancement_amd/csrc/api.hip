@@ -186,7 +186,7 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
 {
     const float eps = 1e-6f;  // six_stadigy.py:198,218
     const int k = p->strategy;
-    UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, p->omega, 1e-6f, 1, P.t0, st));
+    UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, (float)p->omega, 1e-6f, 1, P.t0, st));
     UWIE_TRY(stage_guided(ctx, P, s, p, st));
     // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
     SelectPlan plan;
@@ -243,7 +243,7 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
 {
     UWIE_TRY(launch_quant_gray(d_in, nullptr, P.gray, s, p->gray_shift, st));
     UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
-    UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
+    UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, (float)p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
     UWIE_TRY(stage_guided(ctx, P, s, p, st));
     SelectPlan plan;
     const double q[2] = {p->L_low, p->L_high};
@@ -290,6 +290,152 @@ int check_params(const uwie_params *p)
         UWIE_REQUIRE(p->wb_percentile >= 0.0 && p->wb_percentile <= 100.0, "wb_percentile must be in [0, 100]");
     UWIE_REQUIRE(p->inter_dtype == UWIE_INTER_F64 || p->inter_dtype == UWIE_INTER_FX32, "unknown inter_dtype");
     return UWIE_OK;
+}
+
+
+// ---------------------------------------------------------------- general float images (k_float.hip)
+// Buffers of one float-image call.  T = the image's dtype (float: either surface; double: dict surface only).
+template <class T>
+struct FloatPipe {
+    int32_t *kind;
+    T *A;
+    float *pct;
+    double *pct64;
+    T *xc;          // colour-corrected copy (SIX surface with cast correction)
+    uint8_t *q;     // (x * 255).astype(u8)
+    uint8_t *gray;
+    T *t0;
+    double *t;
+    float *F, *F2;  // SIX: working images, HWC
+    double *F64;    // DICT: recovered image, planar
+    void *scratch;
+    size_t scratch_bytes;
+};
+
+template <class T>
+FloatPipe<T> carve_float(Carver &c, Shape s, const uwie_params *p)
+{
+    FloatPipe<T> P{};
+    const size_t n = (size_t)s.B * s.npx();
+    const bool six = p->surface == UWIE_SURFACE_SIX, dz = dehazes(p);
+    P.kind = c.take<int32_t>(s.B);
+    P.A = c.take<T>((size_t)s.B * 3);
+    P.pct = c.take<float>((size_t)s.B * 3 * kMaxPct);
+    P.pct64 = c.take<double>((size_t)s.B * 3 * kMaxPct);
+    if (six) P.xc = c.take<T>(n * 3);
+    P.q = c.take<uint8_t>(n * 3);
+    if (dz) {
+        P.gray = c.take<uint8_t>(n);
+        P.t0 = c.take<T>(n);
+        P.t = c.take<double>(n);
+    }
+    if (six) {
+        P.F = c.take<float>(n * 3);
+        P.F2 = c.take<float>(n * 3);
+    } else if (dz) {
+        P.F64 = c.take<double>(n * 3);
+    }
+    const int tx = p->tiles_x > 0 ? p->tiles_x : 8, ty = p->tiles_y > 0 ? p->tiles_y : 8;
+    P.scratch_bytes = max5(dz ? float_airlight_ws_bytes(s) : 0, dz ? guided_ws_bytes(s) : 0, select_ws_bytes(s), clahe_ws_bytes(s, tx, ty),
+                           codes_ws_bytes(s, tx, ty));
+    P.scratch = c.take<char>(P.scratch_bytes);
+    return P;
+}
+
+// percentile stretch of a float32 HWC image in place (S6:191-199 / :211-219)
+static int float_stretch(const FloatPipe<float> &P, float *img, Shape s, double lo, double hi, hipStream_t st)
+{
+    const double q[2] = {lo, hi};
+    UWIE_TRY(launch_percentiles_f32(img, 0, s, q, 2, P.pct, P.scratch, st));
+    return launch_stretch_apply_f32(img, P.pct, 2, 0, 1, 1e-6f, img, s, st);
+}
+
+// six_stadigy.py strategies 1-6 on a float32 image (S6:230-285); the result image goes to out_f32 and/or out_u8
+static int run_float_six(uwie_ctx *ctx, const float *d_img, Shape s, const uwie_params *p, const FloatPipe<float> &P, uint8_t *out_u8,
+                         float *out_f32, hipStream_t st)
+{
+    const size_t n3 = (size_t)s.B * s.npx() * 3;
+    const int32_t *kind = nullptr;
+    if (p->forced_cast >= 0) {
+        UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
+        kind = P.kind;
+    } else if (p->cast_correct) {
+        UWIE_TRY(launch_float_cast_classify<float>(d_img, s, P.kind, nullptr, st));
+        kind = P.kind;
+    }
+    const int k = p->strategy;
+    const bool dz = k <= 3;
+    const float *x = d_img;
+    UWIE_TRY(launch_float_prepare<float>(d_img, kind, kind ? P.xc : nullptr, dz ? P.q : nullptr, s, st));
+    if (kind) x = P.xc;
+    float *y = P.F;
+    if (dz) {
+        UWIE_TRY(launch_rgb2gray_u8(P.q, P.gray, (size_t)s.B * s.npx(), p->gray_shift, st));
+        UWIE_TRY(launch_float_airlight<float>(x, P.gray, s, p->min_size, P.A, P.scratch, st));
+        UWIE_TRY(launch_float_trans_init<float>(x, P.A, s, p->omega, (double)1e-6f, 1, P.t0, st));
+        int handled = 0;
+        if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, false));
+        if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+        UWIE_TRY((launch_float_restore<float, float>(x, P.A, P.t, s, y, 0, st)));
+        UWIE_TRY(float_stretch(P, y, s, p->L_low, p->L_high, st));
+        if (k == 3) {
+            UWIE_TRY(float_stretch(P, y, s, p->wb_percentile, 100 - p->wb_percentile, st));
+        } else {
+            UWIE_TRY(launch_clahe_f32(ctx, y, P.F2, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+            y = P.F2;
+            if (k == 1) UWIE_TRY(launch_gamma_f32(y, y, n3, p->gamma, 1, st));
+        }
+    } else if (k == 4) {  // S6:262-268  clahe -> stretch -> white_balance -> gamma
+        UWIE_TRY(launch_clahe_f32(ctx, x, y, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+        UWIE_TRY(float_stretch(P, y, s, p->L_low, p->L_high, st));
+        UWIE_TRY(float_stretch(P, y, s, p->wb_percentile, 100 - p->wb_percentile, st));
+        UWIE_TRY(launch_gamma_f32(y, y, n3, p->gamma, 1, st));
+    } else {  // S6:270-285  [white_balance ->] stretch -> clahe -> gamma
+        UWIE_HIP_CHECK(hipMemcpyAsync(y, x, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (k == 5) UWIE_TRY(float_stretch(P, y, s, p->wb_percentile, 100 - p->wb_percentile, st));
+        UWIE_TRY(float_stretch(P, y, s, p->L_low, p->L_high, st));
+        UWIE_TRY(launch_clahe_f32(ctx, y, P.F2, s, p->clip_limit, p->tiles_x, p->tiles_y, P.scratch, st));
+        y = P.F2;
+        UWIE_TRY(launch_gamma_f32(y, y, n3, p->gamma, 1, st));
+    }
+    if (out_f32) UWIE_HIP_CHECK(hipMemcpyAsync(out_f32, y, n3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (out_u8) UWIE_TRY(launch_quantise_u8(y, out_u8, n3, st));
+    return UWIE_OK;
+}
+
+// enhancement_strategies.py apply_strategy bodies (ES:350-474) on a float32 or float64 image
+template <class T>
+static int run_float_dict(uwie_ctx *ctx, const T *d_img, Shape s, const uwie_params *p, const FloatPipe<T> &P, uint8_t *out_u8,
+                          float *out_f32, double *out_f64, hipStream_t st)
+{
+    UWIE_TRY(launch_float_prepare<T>(d_img, nullptr, (T *)nullptr, P.q, s, st));
+    if (!dehazes(p))  // clahe_enhancement / histogram_equalization start by quantising: code domain from here on
+        return launch_code_strategy(ctx, P.q, nullptr, s, p, out_u8, out_f32, P.scratch, st, out_f64, true);
+    UWIE_TRY(launch_rgb2gray_u8(P.q, P.gray, (size_t)s.B * s.npx(), p->gray_shift, st));
+    UWIE_TRY(launch_float_airlight<T>(d_img, P.gray, s, p->min_size, P.A, P.scratch, st));
+    UWIE_TRY(launch_float_trans_init<T>(d_img, P.A, s, p->omega, 1e-10, 0, P.t0, st));  // ES:221-225: no clip
+    if constexpr (sizeof(T) == 4) {
+        int handled = 0;
+        if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, false));
+        if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+    } else {
+        UWIE_TRY(launch_guided_p64(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
+    }
+    UWIE_TRY((launch_float_restore<T, double>(d_img, P.A, P.t, s, P.F64, 1, st)));
+    SelectPlan plan;
+    const double q[2] = {p->L_low, p->L_high};
+    UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
+    UWIE_TRY(select_run64(plan, P.F64, 1, s, false, st));
+    UWIE_TRY(select_lerp64(plan, s, P.pct64, st));
+    return launch_tail_plain64(P.F64, P.pct64, s, p->apply_gamma, p->gamma, out_u8, out_f32, st, nullptr, out_f64);
+}
+
+template <class T>
+static size_t float_ws_bytes(int batch, int H, int W, const uwie_params *p)
+{
+    Carver c(nullptr);
+    carve_float<T>(c, Shape{batch, H, W}, p);
+    return c.total();
 }
 
 }  // namespace
@@ -404,9 +550,9 @@ int uwie_params_init(uwie_params *p, int surface, int strategy)
     if (surface == UWIE_SURFACE_SIX) {
         p->cast_correct = 1;
         switch (strategy) {  // six_stadigy.py:230-285
-        case 1: p->omega = 0.3f; p->gf_ksize = 20; p->gf_eps = 5e-1; p->L_low = 5; p->L_high = 98; p->clip_limit = 3.0; p->gamma = 1.5; p->apply_gamma = 1; break;
-        case 2: p->omega = 0.5f; p->gf_ksize = 15; p->gf_eps = 5e-1; p->L_low = 15; p->L_high = 95; p->clip_limit = 2.0; break;
-        case 3: p->omega = 0.7f; p->gf_ksize = 10; p->gf_eps = 1e-1; p->L_low = 20; p->L_high = 85; p->wb_percentile = 2; break;
+        case 1: p->omega = 0.3; p->gf_ksize = 20; p->gf_eps = 5e-1; p->L_low = 5; p->L_high = 98; p->clip_limit = 3.0; p->gamma = 1.5; p->apply_gamma = 1; break;
+        case 2: p->omega = 0.5; p->gf_ksize = 15; p->gf_eps = 5e-1; p->L_low = 15; p->L_high = 95; p->clip_limit = 2.0; break;
+        case 3: p->omega = 0.7; p->gf_ksize = 10; p->gf_eps = 1e-1; p->L_low = 20; p->L_high = 85; p->wb_percentile = 2; break;
         case 4: p->clip_limit = 4.0; p->L_low = 10; p->L_high = 95; p->wb_percentile = 3; p->gamma = 1.3; p->apply_gamma = 1; break;
         case 5: p->wb_percentile = 2; p->L_low = 15; p->L_high = 90; p->clip_limit = 1.5; p->gamma = 1.2; p->apply_gamma = 1; break;
         case 6: p->L_low = 5; p->L_high = 98; p->clip_limit = 3.5; p->gamma = 1.4; p->apply_gamma = 1; break;
@@ -417,9 +563,9 @@ int uwie_params_init(uwie_params *p, int surface, int strategy)
     if (surface == UWIE_SURFACE_DICT) {
         p->gf_eps = 0.001;  // estimate_transmission's default; callers never pass it (ES:209,354-358)
         switch (strategy) {  // in-code defaults of ES:350-474
-        case UWIE_DICT_STRONG_DEHAZING: p->omega = 0.5f; p->gf_ksize = 15; p->L_low = 10; p->L_high = 95; break;
-        case UWIE_DICT_MEDIUM_DEHAZING: p->omega = 0.6f; p->gf_ksize = 20; p->L_low = 15; p->L_high = 92; break;
-        case UWIE_DICT_LIGHT_ENHANCEMENT: p->omega = 0.4f; p->gf_ksize = 10; p->L_low = 15; p->L_high = 95; break;
+        case UWIE_DICT_STRONG_DEHAZING: p->omega = 0.5; p->gf_ksize = 15; p->L_low = 10; p->L_high = 95; break;
+        case UWIE_DICT_MEDIUM_DEHAZING: p->omega = 0.6; p->gf_ksize = 20; p->L_low = 15; p->L_high = 92; break;
+        case UWIE_DICT_LIGHT_ENHANCEMENT: p->omega = 0.4; p->gf_ksize = 10; p->L_low = 15; p->L_high = 95; break;
         case UWIE_DICT_CLAHE_ENHANCEMENT: p->clip_limit = 2.0; p->L_low = 20; p->L_high = 85; break;
         case UWIE_DICT_HISTOGRAM_EQUALIZATION: p->L_low = 10; p->L_high = 95; break;
         default: set_error("unknown strategy %d", strategy); return UWIE_E_INVALID;
@@ -572,6 +718,60 @@ int uwie_enhance_u8_f64(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, d
     return run_dict_dehaze(ctx, d_in, s, p, P, d_out_u8, nullptr, st, d_out_f64);
 }
 
+
+size_t uwie_workspace_bytes_float(int batch, int H, int W, const uwie_params *p, int elem_bytes)
+{
+    if (!shape_ok(batch, H, W) || !p || (elem_bytes != 4 && elem_bytes != 8)) return 0;
+    return elem_bytes == 4 ? float_ws_bytes<float>(batch, H, W, p) : float_ws_bytes<double>(batch, H, W, p);
+}
+
+int uwie_enhance_f32(uwie_ctx *ctx, const float *d_img, uint8_t *d_out_u8, float *d_out_f32, double *d_out_f64, int batch, int H, int W,
+                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && (d_out_u8 || d_out_f32 || d_out_f64), "enhance_f32: NULL context or image pointer");
+    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_TRY(check_params(p));
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    FloatPipe<float> P = carve_float<float>(c, s, p);
+    UWIE_CHECK_WS(c.total());
+    if (p->surface == UWIE_SURFACE_SIX) {
+        UWIE_REQUIRE(!d_out_f64, "enhance_f32: the six_stadigy strategies return float32 images");
+        return run_float_six(ctx, d_img, s, p, P, d_out_u8, d_out_f32, (hipStream_t)stream);
+    }
+    return run_float_dict<float>(ctx, d_img, s, p, P, d_out_u8, d_out_f32, d_out_f64, (hipStream_t)stream);
+}
+
+int uwie_enhance_f64(uwie_ctx *ctx, const double *d_img, uint8_t *d_out_u8, double *d_out_f64, int batch, int H, int W,
+                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && (d_out_u8 || d_out_f64), "enhance_f64: NULL context or image pointer");
+    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_TRY(check_params(p));
+    UWIE_REQUIRE(p->surface == UWIE_SURFACE_DICT, "enhance_f64: float64 images are the dict surface's (six_stadigy.py works on float32, S6:406)");
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    FloatPipe<double> P = carve_float<double>(c, s, p);
+    UWIE_CHECK_WS(c.total());
+    return run_float_dict<double>(ctx, d_img, s, p, P, d_out_u8, nullptr, d_out_f64, (hipStream_t)stream);
+}
+
+int uwie_color_correct_f32(uwie_ctx *ctx, const float *d_img, const int32_t *d_kind, float *d_out, int batch, int H, int W, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && d_kind && d_out, "color_correct_f32: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    return launch_float_prepare<float>(d_img, d_kind, d_out, nullptr, Shape{batch, H, W}, (hipStream_t)stream);
+}
+
+int uwie_cast_classify_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, int W, int32_t *d_kind, float *d_mean_rgb, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_img && (d_kind || d_mean_rgb), "cast_classify_f32: NULL pointer");
+    UWIE_CHECK_SHAPE(batch, H, W);
+    return launch_float_cast_classify<float>(d_img, Shape{batch, H, W}, d_kind, d_mean_rgb, (hipStream_t)stream);
+}
+
 int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, int32_t *d_kind, int batch, int H, int W,
                         const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream)
 {
@@ -693,7 +893,7 @@ int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
     const Shape s{batch, H, W};
     hipStream_t st = (hipStream_t)stream;
     const bool six = p->surface == UWIE_SURFACE_SIX;
-    if (d_t0) UWIE_TRY(launch_trans_init(d_in, d_kind, d_A, s, p->omega, six ? 1e-6f : 1e-10f, six ? 1 : 0, d_t0, st));
+    if (d_t0) UWIE_TRY(launch_trans_init(d_in, d_kind, d_A, s, (float)p->omega, six ? 1e-6f : 1e-10f, six ? 1 : 0, d_t0, st));
     if (d_gray) UWIE_TRY(launch_quant_gray(d_in, d_kind, d_gray, s, p->gray_shift, st));
     return UWIE_OK;
 }

@@ -318,8 +318,21 @@ int launch_tail_plain64(const double *d_planar, const double *d_pct, Shape s, in
 // k_codes.hip: strategies 4-6 of six_stadigy.py and the clahe / histogram-equalisation strategies of
 // enhancement_strategies.py, evaluated on 8-bit codes (per image and channel LUT chains + histograms)
 size_t codes_ws_bytes(Shape s, int tx, int ty);
+// quantised: d_in is (img * 255).astype(u8) of a general float image instead of the u8 frame the float image came from
 int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
-                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64 = nullptr);
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64 = nullptr,
+                         bool quantised = false);
+
+// k_float.hip: the front half of the strategies on general (not u8-derived) float images, T = float or double
+size_t float_airlight_ws_bytes(Shape s);
+template <class T> int launch_float_prepare(const T *d_x, const int32_t *d_kind, T *d_xc, uint8_t *d_q, Shape s, hipStream_t st);
+template <class T> int launch_float_cast_classify(const T *d_x, Shape s, int32_t *d_kind, float *d_mean, hipStream_t st);
+template <class T> int launch_float_airlight(const T *d_x, const uint8_t *d_gray, Shape s, int min_size, T *d_A, void *ws, hipStream_t st);
+template <class T> int launch_float_trans_init(const T *d_x, const T *d_A, Shape s, double omega, double norm_eps, int pre_clip, T *d_t0,
+                                               hipStream_t st);
+template <class T, class OUT> int launch_float_restore(const T *d_x, const T *d_A, const double *d_t, Shape s, OUT *d_out, int planar,
+                                                       hipStream_t st);
+int launch_guided_p64(const uint8_t *d_gray, const double *d_t0, Shape s, int k, double eps, double *d_t, void *ws, hipStream_t st);
 
 // k_tail.hip
 int launch_restore(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,

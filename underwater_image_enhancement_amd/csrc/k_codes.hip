@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_frame_hist(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------ the chain
-enum { OP_INIT = 1, OP_INITQUANT, OP_FROMCODE, OP_QUANT, OP_EQUALIZE, OP_STRETCH, OP_GAMMA };
+enum { OP_INIT = 1, OP_INITQUANT, OP_FROMCODE, OP_QUANT, OP_EQUALIZE, OP_STRETCH, OP_GAMMA, OP_INITCODE };
 struct ChainOp {
     int op, mode;
     uint32_t rank[4];  // STRETCH: prev/next of the low percentile, prev/next of the high percentile
@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(256) k_code_chain(const uint32_t *__restrict__
             break;
         case OP_INITQUANT:  // (x * 255).astype(u8) of the float32 frame
             code = quant_u8(px_val(u, atten));
+            break;
+        case OP_INITCODE:  // the frame IS (img * 255).astype(u8) of a general float image (k_float.hip)
+            code = u;
             break;
         case OP_FROMCODE:  // .astype(T) / 255.0
             val = (T)code / (T)255;
@@ -329,7 +332,7 @@ int launch_frame_hist(const uint8_t *d_in, Shape s, uint32_t *d_hist, hipStream_
 
 // u8 quantisation, eps 1e-10, gamma = clip(x**(1/g))); otherwise S6 arithmetic (float32, eps 1e-6, x**g).
 int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, Shape s, const uwie_params *p,
-                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64)
+                         uint8_t *d_out_u8, float *d_out_f32, void *ws, hipStream_t st, double *d_out_f64, bool quantised)
 {
     Carver c(ws);
     const int tx = p->tiles_x, ty = p->tiles_y;
@@ -349,8 +352,13 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
     pre.eps = post.eps = es ? 1e-10 : (double)1e-6f;
     bool clahe = true, post_needs_hist = false;
     ChainOp gam = simple_op(OP_GAMMA, es ? 2 : 1, es ? 1.0 / p->gamma : (double)(float)p->gamma);
+    const int init_q = quantised ? OP_INITCODE : OP_INITQUANT;  // d_in = the u8 frame, or the quantised float image
+    if (quantised && !(es || k == 4)) {
+        set_error("a pre-quantised frame only fits the strategies that start by quantising (S6 strategy 4, dict clahe / hist-eq)");
+        return UWIE_E_INVALID;
+    }
     if (!es && k == 4) {  // S6:262-268  clahe -> stretch -> white_balance -> gamma
-        pre.ops[pre.nops++] = simple_op(OP_INITQUANT);
+        pre.ops[pre.nops++] = simple_op(init_q);
         post.ops[post.nops++] = simple_op(OP_FROMCODE);
         stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, false);
         stretch_op(&post.ops[post.nops++], n, wb, 100 - wb, false);
@@ -370,14 +378,14 @@ int launch_code_strategy(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_ki
         post.ops[post.nops++] = simple_op(OP_FROMCODE);
         post.ops[post.nops++] = gam;
     } else if (es && k == UWIE_DICT_CLAHE_ENHANCEMENT) {  // ES:400-420
-        pre.ops[pre.nops++] = simple_op(OP_INITQUANT);
+        pre.ops[pre.nops++] = simple_op(init_q);
         post.ops[post.nops++] = simple_op(OP_FROMCODE);
         stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, true);
         if (p->apply_gamma) post.ops[post.nops++] = gam;
         post_needs_hist = true;
     } else if (es && k == UWIE_DICT_HISTOGRAM_EQUALIZATION) {  // ES:461-474: everything is one LUT of the input frame
         clahe = false;
-        post.ops[post.nops++] = simple_op(OP_INITQUANT);
+        post.ops[post.nops++] = simple_op(init_q);
         post.ops[post.nops++] = simple_op(OP_EQUALIZE);
         post.ops[post.nops++] = simple_op(OP_FROMCODE);
         stretch_op(&post.ops[post.nops++], n, p->L_low, p->L_high, true);

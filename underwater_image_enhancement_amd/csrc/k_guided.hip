@@ -39,13 +39,16 @@ struct SrcPlanes2 {
     }
     __device__ static __forceinline__ double plane(const Raw &r, int w, const double *) { return w == 0 ? r.a : r.b; }
 };
-struct SrcGuide {  // I = gray/255 (float64), p = t0 (float32 -> float64); planes I, p, I*p, I*I (six_stadigy.py:28-36)
+// I = gray/255 (float64), p = t0 (.astype(float64): float32 from the u8-derived frame, float64 for a float64 image on the
+// dict surface); planes I, p, I*p, I*I (six_stadigy.py:28-36)
+template <class TP>
+struct SrcGuideT {
     const uint8_t *gray;
-    const float *t0;
+    const TP *t0;
     int H, W;
     static constexpr int NP = 4;
     struct Raw {
-        float t0;
+        TP t0;
         uint32_t g;
     };
     __device__ __forceinline__ Raw load(int b, int y, int x) const
@@ -59,6 +62,7 @@ struct SrcGuide {  // I = gray/255 (float64), p = t0 (float32 -> float64); plane
         return w == 0 ? I : w == 1 ? p : w == 2 ? I * p : I * I;
     }
 };
+using SrcGuide = SrcGuideT<float>;
 
 // Row pass: RowSum<double,double> of cv2.boxFilter.  One workgroup owns 64 rows of one image; wave w owns plane w
 // and lane r owns row r, so every row's running sum is the literal left-to-right chain
@@ -256,15 +260,15 @@ size_t guided_ws_bytes(Shape s)
     return c.total();
 }
 
-int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, void *ws,
-                  hipStream_t st)
+template <class TP>
+static int launch_guided_t(const uint8_t *d_gray, const TP *d_t0, Shape s, int k, double eps, double *d_t, void *ws, hipStream_t st)
 {
     Carver c(ws);
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
     const dim3 grows(cdiv(s.H, kTR), s.B), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
-    UWIE_LAUNCH(k_box_rows<SrcGuide>, grows, dim3(256), 0, st, SrcGuide{d_gray, d_t0, s.H, s.W}, rs, n, k);
+    UWIE_LAUNCH(k_box_rows<SrcGuideT<TP>>, grows, dim3(256), 0, st, SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
@@ -273,6 +277,16 @@ int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, doub
     UWIE_LAUNCH(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
+}
+
+int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, void *ws, hipStream_t st)
+{
+    return launch_guided_t<float>(d_gray, d_t0, s, k, eps, d_t, ws, st);
+}
+// float64 p (float64 images on the dict surface): the exact-order kernels only
+int launch_guided_p64(const uint8_t *d_gray, const double *d_t0, Shape s, int k, double eps, double *d_t, void *ws, hipStream_t st)
+{
+    return launch_guided_t<double>(d_gray, d_t0, s, k, eps, d_t, ws, st);
 }
 
 }  // namespace uwie

@@ -12,18 +12,20 @@ constexpr int kNpChunk = 8192;     // NumPy's reduction buffer size
 constexpr int kMaxLeaves = 192;    // a leaf of the pairwise recursion holds 64..128 elements: at most 127 per chunk
 constexpr int kTreeLevels = 10;    // depth of that recursion for n < 8192 is at most 8
 
-struct PairwiseTree {  // LDS scratch of one wavefront
+template <class T>
+struct PairwiseTreeT {  // LDS scratch of one wavefront
     uint16_t off[kTreeLevels + 1][kMaxLeaves], len[kTreeLevels + 1][kMaxLeaves], child[kTreeLevels][kMaxLeaves];
     int cnt[kTreeLevels + 1];
-    float val[2][3][kMaxLeaves];
+    T val[2][3][kMaxLeaves];
 };
+using PairwiseTree = PairwiseTreeT<float>;  // float32 data (the u8-derived frame); float64 images use PairwiseTreeT<double>
 
 // Three sums at once over a ragged chunk of `len` < 8192 elements, one wavefront (blockDim.x == 64, all lanes call).
 // The tree is expanded level by level with every lane working (a node list per level, kept in left-to-right order: a
 // split node is replaced by its two children in place), leaves are summed one per lane by `leaf(off, len, out3)`, and
 // the sums are folded back level by level (value = left + right, as the recursion returns them).  Result in lane 0.
-template <class Leaf>
-__device__ void pairwise_ragged(int len, int lane, PairwiseTree &t, Leaf leaf, float res[3])
+template <class T, class Leaf>
+__device__ void pairwise_ragged(int len, int lane, PairwiseTreeT<T> &t, Leaf leaf, T res[3])
 {
     int nlev = 0;
     if (lane == 0) { t.off[0][0] = 0; t.len[0][0] = (uint16_t)len; t.cnt[0] = 1; }
@@ -60,7 +62,7 @@ __device__ void pairwise_ragged(int len, int lane, PairwiseTree &t, Leaf leaf, f
     }
     const int nLeaf = t.cnt[nlev];
     for (int i = lane; i < nLeaf; i += 64) {
-        float s[3];
+        T s[3];
         leaf(t.off[nlev][i], t.len[nlev][i], s);
         t.val[nlev & 1][0][i] = s[0]; t.val[nlev & 1][1][i] = s[1]; t.val[nlev & 1][2][i] = s[2];
     }
@@ -72,7 +74,7 @@ __device__ void pairwise_ragged(int len, int lane, PairwiseTree &t, Leaf leaf, f
             const bool split = t.len[lv][i] > 128;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float a = t.val[(lv + 1) & 1][c][ch];
+                const T a = t.val[(lv + 1) & 1][c][ch];
                 t.val[lv & 1][c][i] = split ? a + t.val[(lv + 1) & 1][c][ch + 1] : a;
             }
         }
@@ -81,7 +83,8 @@ __device__ void pairwise_ragged(int len, int lane, PairwiseTree &t, Leaf leaf, f
     res[0] = t.val[0][0][0]; res[1] = t.val[0][1][0]; res[2] = t.val[0][2][0];
 }
 
-__device__ __forceinline__ float tree8(const float *r)
+template <class T>
+__device__ __forceinline__ T tree8(const T *r)
 {
     return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
 }

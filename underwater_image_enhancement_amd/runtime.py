@@ -128,6 +128,40 @@ class Device:
                                            _ptr(ws), ws.numel(), self.stream()))
         return out, outf
 
+    def enhance_float(self, img, p: UwieParams, want: str = "native"):
+        """General (not u8-derived) float images [B,H,W,3], float32 (either surface) or float64 (dict surface): returns
+        (uint8 [B,H,W,3], float image): float32 for the six_stadigy surface, float64 for the dict surface."""
+        assert img.dim() == 4 and img.shape[-1] == 3 and img.is_contiguous(), "expected contiguous [B,H,W,3]"
+        B, H, W = (int(v) for v in img.shape[:3])
+        six = p.surface == _lib.SURFACE_SIX
+        eb = 4 if img.dtype == torch.float32 else 8
+        ws = self.workspace(self.lib.uwie_workspace_bytes_float(B, H, W, ctypes.byref(p), eb))
+        out = self.empty((B, H, W, 3), torch.uint8)
+        if img.dtype == torch.float32:
+            of32 = self.empty((B, H, W, 3), torch.float32) if six else None
+            of64 = None if six else self.empty((B, H, W, 3), torch.float64)
+            check(self.lib.uwie_enhance_f32(self._ctx, _ptr(img), _ptr(out), _ptr(of32), _ptr(of64), B, H, W, ctypes.byref(p),
+                                            _ptr(ws), ws.numel(), self.stream()))
+            return out, (of32 if six else of64)
+        assert img.dtype == torch.float64
+        of64 = self.empty((B, H, W, 3), torch.float64)
+        check(self.lib.uwie_enhance_f64(self._ctx, _ptr(img), _ptr(out), _ptr(of64), B, H, W, ctypes.byref(p), _ptr(ws),
+                                        ws.numel(), self.stream()))
+        return out, of64
+
+    def cast_classify_f32(self, img):
+        B, H, W = (int(v) for v in img.shape[:3])
+        kind = self.empty((B,), torch.int32)
+        mean = self.empty((B, 3), torch.float32)
+        check(self.lib.uwie_cast_classify_f32(self._ctx, _ptr(img), B, H, W, _ptr(kind), _ptr(mean), self.stream()))
+        return kind, mean
+
+    def color_correct_f32(self, img, kind):
+        B, H, W = (int(v) for v in img.shape[:3])
+        out = self.empty((B, H, W, 3), torch.float32)
+        check(self.lib.uwie_color_correct_f32(self._ctx, _ptr(img), _ptr(kind), _ptr(out), B, H, W, self.stream()))
+        return out
+
     def enhance_all_u8(self, frames, cast_correct: bool = True):
         """frames: uint8 cuda tensor [B,H,W,3] -> (uint8 [6,B,H,W,3] = strategies 1..6, int32 [B] cast kinds)."""
         B, H, W = self._bhw(frames)
