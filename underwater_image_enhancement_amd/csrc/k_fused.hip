@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
                 }
             }
         }
-        if (COLLECT) flush(false);
+        // (a barrier per trip would tie the block's wavefronts together every 1024 pixels: the stages hold 128 / 256
+        // candidates per window against ~3 arriving per trip, and a full stage overflows straight into the list)
+        if (COLLECT && (it & 7) == 7) flush(false);
     }
     if (!ghist) return;
     if (COLLECT) flush(true);
