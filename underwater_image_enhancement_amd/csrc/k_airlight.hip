@@ -13,6 +13,8 @@
 #include "devutil.h"
 #include "pairwise_tree.h"
 
+#include <cstdlib>
+
 namespace uwie {
 
 namespace {
@@ -376,20 +378,343 @@ __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Regio
     }
 }
 
-// get_brightest_pixel (six_stadigy.py:160-165): argmax of (r+g)+b over the leaf, first maximum in raster order.
-__global__ void __launch_bounds__(64) k_brightest(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
-                                                  const Region *__restrict__ blk, int H, int W, float *__restrict__ A)
+// ---- the small levels in one launch ---------------------------------------------------------------------------------
+// Once a quadrant holds at most one NumPy buffer (8192 elements) a level is a few microseconds of work behind nine
+// launches, and with min_size 1 there are seven such levels at 1080p and at 4K.  k_q_tail walks them all: one workgroup
+// of 16 wavefronts per image, four wavefronts per quadrant, everything a level touches staged in LDS.
+// Per quadrant (its own LDS slice): the RGB bytes come in with coalesced loads; the pairwise recursion's leaves are
+// summed by eight lanes each -- lane j owns NumPy's accumulator r[j], the three-level combination of the eight is an
+// xor-butterfly, the tail elements follow sequentially -- and folded back by one wavefront (pairwise_tree.h); the same
+// again for the squared deviations; then the slice is reused for the gray bytes and one 16-bit word per pixel
+//   [10:0] |dx|+|dy|   [12:11] direction (0 horizontal, 1 vertical, 2 diagonal dx*dy>=0, 3 diagonal dx*dy<0)
+//   [14:13] state after suppression (0 none, 1 weak, 2 strong -> edge)
+// for cv2.Canny on the quadrant (Sobel with the quadrant's border replicated, magnitudes outside it 0, OpenCV's
+// fixed-point tan(22.5 deg)).  Hysteresis, only when the quadrant has a strong pixel at all: one wavefront repeats
+// forward / backward sweeps in raster order, 64 consecutive pixels per step; inside a step the horizontal runs are
+// closed with an occluded fill on the 64-bit ballots, the rows above and below are read back from LDS.  The sweeps stop
+// when one changes nothing, which is the fixed point cv2.Canny's stack reaches.
+// The four scores meet in LDS, every thread takes the first maximum and steps into that quadrant; the leaf's brightest
+// pixel is taken at the end.
+typedef PairwiseTreeT<float, 128, 8> TailTree;
+constexpr int kTailSub = 4;                                    // wavefronts per quadrant
+constexpr int kTailPixBytes = 3 * kNpChunk;                    // RGB of a quadrant; later its gray bytes + 16-bit words
+constexpr int kTailTreeBytes = (int)((sizeof(TailTree) + 15) & ~size_t(15));
+constexpr int kTailQuadBytes = kTailPixBytes + kTailTreeBytes;
+
+__device__ __forceinline__ void tail_wave_sync()
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const Region r = blk[b];
-    const int k = kind ? kind[b] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// rows x rowbytes bytes (global, row pitch `pitch`) -> dense LDS, by the `nl` lanes of a quadrant (this one is `ql`):
+// dword loads, up to eight in flight per lane; (row, dword) advance without a division per element
+__device__ void tail_stage(const uint8_t *__restrict__ src, size_t pitch, int rows, int rowbytes, uint8_t *dst, int ql, int nl)
+{
+    const int dpr = (rowbytes + 3) >> 2, total = rows * dpr;
+    const int ystep = nl / dpr, dstep = nl - ystep * dpr;
+    int y = ql / dpr, d = ql - y * dpr;
+    for (int base = 0; base < total; base += 8 * nl) {
+        uint32_t v[8];
+        int off[8], nb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (base + u * nl >= total) { nb[u] = 0; continue; }  // (uniform)
+            const int bx = 4 * d;
+            nb[u] = y < rows ? min(4, rowbytes - bx) : 0;
+            off[u] = y * rowbytes + bx;
+            const uint8_t *p = src + (size_t)y * pitch + bx;
+            v[u] = 0;
+            if (nb[u] == 4) v[u] = *reinterpret_cast<const u32_unaligned *>(p);
+            else
+                for (int j = 0; j < nb[u]; ++j) v[u] |= (uint32_t)p[j] << (8 * j);
+            y += ystep;
+            d += dstep;
+            if (d >= dpr) { d -= dpr; ++y; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            for (int j = 0; j < nb[u]; ++j) dst[off[u] + j] = (uint8_t)(v[u] >> (8 * j));
+    }
+}
+
+// Leaf sums of the pairwise recursion (level nlev of `tree`), eight lanes per leaf; rgb: the quadrant's bytes in raster
+// order.  grp: this lane's group among the quadrant's ngrp groups, sub: its accumulator.
+template <bool VAR>
+__device__ void tail_leaves(const Elem<VAR> &el, const uint8_t *rgb, TailTree &tree, int nlev, int grp, int ngrp, int sub)
+{
+    const int nLeaf = tree.cnt[nlev];
+    for (int i = grp; i < nLeaf; i += ngrp) {
+        const int len = tree.len[nlev][i];
+        const uint8_t *p = rgb + 3 * (int)tree.off[nlev][i];
+        float r[3];
+        if (len < 8) {
+            r[0] = r[1] = r[2] = 0.0f;
+            for (int e = 0; e < len; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[c] += el.get(p, 3 * e + c, c);
+        } else {
+            const int n8 = len - (len % 8);
+            // the (at most 16) elements of accumulator `sub` are read up front: one LDS round trip per leaf, not per element
+            uint8_t raw[16][3];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int e = min(8 * it + sub, len - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) raw[it][c] = p[3 * e + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r[c] = el.get(raw[0], c, c);
+#pragma unroll
+            for (int it = 1; it < 16; ++it)
+                if (8 * it + sub < n8) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) r[c] += el.get(raw[it], c, c);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+                r[c] += __shfl_xor(r[c], 1);
+                r[c] += __shfl_xor(r[c], 2);
+                r[c] += __shfl_xor(r[c], 4);
+            }
+            for (int e = n8; e < len; ++e)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[c] += el.get(p, 3 * e + c, c);
+        }
+        if (sub == 0) {
+            tree.val[nlev & 1][0][i] = r[0]; tree.val[nlev & 1][1][i] = r[1]; tree.val[nlev & 1][2][i] = r[2];
+        }
+    }
+}
+
+// Sobel gradients of rows [r0, r1) of the quadrant: a lane walks down a column with the separable row terms of the
+// three rows it needs in registers.  Writes magnitude | direction, state 0.
+__device__ void tail_gradients(const uint8_t *sg, uint16_t *st, int rows, int cols, int r0, int r1, int lane)
+{
+    for (int x = lane; x < cols; x += 64) {
+        const int xm = max(x - 1, 0), xp = min(x + 1, cols - 1);
+        auto hrow = [&](int y, int &d, int &s) {
+            const int o = min(max(y, 0), rows - 1) * cols;
+            const int a = sg[o + xm], b = sg[o + x], c = sg[o + xp];
+            d = c - a;
+            s = a + 2 * b + c;
+        };
+        int d0, s0, d1, s1, d2, s2;
+        hrow(r0 - 1, d0, s0);
+        hrow(r0, d1, s1);
+#pragma unroll 4
+        for (int y = r0; y < r1; ++y) {
+            hrow(y + 1, d2, s2);
+            const int dx = d0 + 2 * d1 + d2, dy = s2 - s0;
+            const int ax = abs(dx), ay = abs(dy) << 15;
+            const int tg22x = ax * 13573;  // (int)(tan(22.5deg) * 2^15 + 0.5)
+            const int dir = ay < tg22x ? 0 : ay > tg22x + (ax << 16) ? 1 : (dx ^ dy) < 0 ? 3 : 2;
+            st[y * cols + x] = (uint16_t)((ax + abs(dy)) | (dir << 11));
+            d0 = d1; s0 = s1; d1 = d2; s1 = s2;
+        }
+    }
+}
+
+// Non-maximum suppression and the double threshold for rows [r0, r1); returns whether this lane kept a strong pixel.
+__device__ bool tail_suppress(uint16_t *st, int rows, int cols, int r0, int r1, int lane, int low, int high)
+{
+    bool strong = false;
+    for (int y = r0; y < r1; ++y)
+        for (int x = lane; x < cols; x += 64) {
+            const int e = y * cols + x;
+            const int w = st[e], m = w & 2047, dir = (w >> 11) & 3;
+            if (m <= low) continue;
+            int o1, o2;  // the two neighbours along the gradient
+            bool in1, in2;
+            if (dir == 0) { o1 = -1; o2 = 1; in1 = x > 0; in2 = x + 1 < cols; }
+            else if (dir == 1) { o1 = -cols; o2 = cols; in1 = y > 0; in2 = y + 1 < rows; }
+            else if (dir == 2) { o1 = -cols - 1; o2 = cols + 1; in1 = y > 0 && x > 0; in2 = y + 1 < rows && x + 1 < cols; }
+            else { o1 = -cols + 1; o2 = cols - 1; in1 = y > 0 && x + 1 < cols; in2 = y + 1 < rows && x > 0; }
+            const int n1 = in1 ? st[e + o1] & 2047 : 0, n2 = in2 ? st[e + o2] & 2047 : 0;
+            if (m > n1 && (m > n2 || (dir < 2 && m == n2))) {
+                st[e] = (uint16_t)(w | ((m > high ? 2 : 1) << 13));  // the magnitude bits stay: neighbours still read them
+                strong = strong || m > high;
+            }
+        }
+    return strong;
+}
+
+// Hysteresis on the state words, one wavefront; returns the number of edge pixels.
+__device__ uint32_t tail_hysteresis(uint16_t *st, int rows, int cols, int lane)
+{
+    const int n = rows * cols, nsteps = (n + 63) / 64;
+    for (int sweep = 0;; ++sweep) {
+        bool changed = false;
+        for (int k = 0; k < nsteps; ++k) {
+            const int step = (sweep & 1) ? nsteps - 1 - k : k;
+            const int e = step * 64 + lane;
+            const bool in = e < n;
+            const int state = in ? (st[e] >> 13) & 3 : 0;
+            const uint64_t weak = __ballot(state == 1);
+            if (!weak) continue;
+            const int y = in ? e / cols : 0, x = in ? e - y * cols : 0;
+            bool hit = false;
+            if (state == 1) {
+                const bool up = y > 0, dn = y + 1 < rows, lf = x > 0, rt = x + 1 < cols;
+                auto S = [&](int o) { return (st[e + o] >> 13) == 2; };
+                hit = (up && (S(-cols) || (lf && S(-cols - 1)) || (rt && S(-cols + 1)))) ||
+                      (dn && (S(cols) || (lf && S(cols - 1)) || (rt && S(cols + 1)))) || (lf && S(-1)) || (rt && S(1));
+            }
+            // close the horizontal runs inside the step: a weak pixel next to an edge pixel of the same row is an edge
+            uint64_t f = __ballot(state == 2 || hit);
+            uint64_t pu = weak & ~__ballot(x == 0);               // may take from the pixel before it
+            uint64_t pd = weak & ~__ballot(in && x == cols - 1);  // may take from the pixel after it
+            // occluded fill towards higher then lower lanes: every seed reaches both ends of its run
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                f |= pu & (f << sft);
+                pu &= pu << sft;
+            }
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                f |= pd & (f >> sft);
+                pd &= pd >> sft;
+            }
+            if (state == 1 && ((f >> lane) & 1)) {
+                st[e] = (uint16_t)((st[e] & 0x1fff) | (2 << 13));
+                changed = true;
+            }
+            tail_wave_sync();
+        }
+        if (!__any(changed)) break;
+    }
+    uint32_t cnt = 0;
+    for (int e = lane; e < n; e += 64) cnt += (st[e] >> 13) == 2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    return cnt;
+}
+
+__global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                           const uint8_t *__restrict__ gray, Region *__restrict__ blk, int H,
+                                                           int W, int level0, int min_size, TraceRec *__restrict__ trace,
+                                                           float *__restrict__ A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tail_lds[];
+    __shared__ double s_q[4];
+    __shared__ float s_sum[4][3];
+    __shared__ int s_strong[4], s_nlev[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int qd = wid / kTailSub, sw = wid % kTailSub, ql = sw * 64 + lane;  // quadrant, wavefront and lane inside it
+    uint8_t *pix = tail_lds + (size_t)qd * kTailQuadBytes;
+    TailTree &tree = *reinterpret_cast<TailTree *>(pix + kTailPixBytes);
+    uint8_t *sg = pix;                                                  // after the sums: gray bytes ...
+    uint16_t *st = reinterpret_cast<uint16_t *>(pix + kNpChunk);        // ... and the state words
+    Region k = blk[b];
+    const int knd = kind ? kind[b] : 0;
     const uint8_t *img = in + (size_t)b * H * W * 3;
-    const int n = r.rows * r.cols;
+    const uint8_t *g = gray + (size_t)b * H * W;
+    for (int level = level0; level < kMaxLevels; ++level) {
+        if (k.rows <= min_size || k.cols <= min_size) break;  // six_stadigy.py:76
+        const int mr = k.rows / 2, mc = k.cols / 2;           // six_stadigy.py:85-86
+        const Region r = qd == 0   ? Region{b, k.y0, k.x0, mr, mc}
+                         : qd == 1 ? Region{b, k.y0, k.x0 + mc, mr, k.cols - mc}
+                         : qd == 2 ? Region{b, k.y0 + mr, k.x0, k.rows - mr, mc}
+                                   : Region{b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc};
+        const int n = r.rows * r.cols;
+#ifdef UWIE_TAIL_PROF
+        const uint64_t c0 = wall_clock64();
+        const uint64_t k0 = clock64();
+#endif
+        // compute_Q (six_stadigy.py:116-157): sums, means, squared deviations
+        int nlev = 0;
+        if (sw == 0) {
+            nlev = pairwise_build<float, 128, 8, true>(n, lane, tree);
+            if (lane == 0) s_nlev[qd] = nlev;
+        }
+        if (threadIdx.x < 4) s_strong[threadIdx.x] = 0;
+        tail_stage(img + ((size_t)r.y0 * W + r.x0) * 3, (size_t)W * 3, r.rows, r.cols * 3, pix, ql, 64 * kTailSub);
+        __syncthreads();
+        nlev = s_nlev[qd];
+        float S[3], V[3];
+        {
+            Elem<false> el;
+            el.img = nullptr; el.W = 0; el.kind = knd;
+            tail_leaves<false>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
+        }
+        __syncthreads();
+        if (sw == 0) {
+            pairwise_combine<float, 128, 8, true>(nlev, lane, tree, S);
+            if (lane < 3) s_sum[qd][lane] = S[lane];
+        }
+        __syncthreads();
+        {
+            Elem<true> el;
+            el.img = nullptr; el.W = 0; el.kind = knd;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                S[c] = s_sum[qd][c];
+                el.mean[c] = (float)((double)S[c] / (double)n);  // numpy/_core/_methods.py:_mean
+            }
+            tail_leaves<true>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
+        }
+        __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t c1 = wall_clock64();
+#endif
+        // the RGB bytes are done with: gray comes in while one wavefront folds the squared deviations
+        if (sw == 0) pairwise_combine<float, 128, 8, true>(nlev, lane, tree, V);
+        else tail_stage(g + (size_t)r.y0 * W + r.x0, (size_t)W, r.rows, r.cols, sg, ql - 64, 64 * (kTailSub - 1));
+        __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t c2 = wall_clock64();
+#endif
+        // cv2.Canny(gray, 50, 150) (six_stadigy.py:150): the quadrant's rows are split over its wavefronts
+        const int r0 = sw * r.rows / kTailSub, r1 = (sw + 1) * r.rows / kTailSub;
+        tail_gradients(sg, st, r.rows, r.cols, r0, r1, lane);
+        __syncthreads();
+        if (__any(tail_suppress(st, r.rows, r.cols, r0, r1, lane, 50, 150)) && lane == 0) s_strong[qd] = 1;
+        __syncthreads();
+        if (sw == 0) {
+            const uint32_t edges = s_strong[qd] ? tail_hysteresis(st, r.rows, r.cols, lane) : 0u;  // no strong pixel: no edge
+            if (lane == 0) {
+                const float t1 = ((S[0] + S[1]) + S[2]) / (float)(3 * (long long)n);
+                const float t2 = ((S[2] + S[1]) - 2.0f * S[0]) / (float)n;
+                const float v0 = V[0] / (float)n, v1 = V[1] / (float)n, v2 = V[2] / (float)n;
+                const float t3 = ((v0 + v1) + v2) / 3.0f;
+                const double t4 = (double)edges / (double)n;  // int64 / int -> float64
+                s_q[qd] = (double)((t1 + t2) - t3) - t4;
+            }
+        }
+        __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t c3 = wall_clock64();
+#endif
+        double score[4];
+        for (int q = 0; q < 4; ++q) score[q] = s_q[q];
+        int arg = 0;
+        for (int q = 1; q < 4; ++q)
+            if (score[q] > score[arg]) arg = q;  // np.argmax: first maximum
+        if (trace && threadIdx.x == 0) {
+            TraceRec &t = trace[b * kMaxLevels + level];
+            t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
+            for (int q = 0; q < 4; ++q) t.score[q] = score[q];
+#ifdef UWIE_TAIL_PROF  // 100 MHz ticks: sums, gray load, Canny
+            t.score[0] = (double)(c1 - c0); t.score[1] = (double)(c2 - c1); t.score[2] = (double)(c3 - c2);
+            t.score[3] = (double)(clock64() - k0) / (double)(wall_clock64() - c0);  // shader clocks per 10 ns
+#endif
+        }
+        k = arg == 0   ? Region{b, k.y0, k.x0, mr, mc}
+            : arg == 1 ? Region{b, k.y0, k.x0 + mc, mr, k.cols - mc}
+            : arg == 2 ? Region{b, k.y0 + mr, k.x0, k.rows - mr, mc}
+                       : Region{b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc};
+        __syncthreads();  // s_q and the slices are rewritten by the next level
+    }
+    if (wid != 0) return;
+    if (lane == 0) blk[b] = k;
+    // get_brightest_pixel (six_stadigy.py:160-165): argmax of (r+g)+b over the leaf, first maximum in raster order
+    const int n = k.rows * k.cols;
     float best = -1.0f;
     int bi = 0x7fffffff;
     for (int e = lane; e < n; e += 64) {
-        const uint8_t *p = img + ((size_t)(r.y0 + e / r.cols) * W + r.x0 + e % r.cols) * 3;
-        const float v = (px_val(p[0], false) + px_val(p[1], px_atten(k, 1))) + px_val(p[2], px_atten(k, 2));
+        const uint8_t *p = img + ((size_t)(k.y0 + e / k.cols) * W + k.x0 + e % k.cols) * 3;
+        const float v = (px_val(p[0], false) + px_val(p[1], px_atten(knd, 1))) + px_val(p[2], px_atten(knd, 2));
         if (v > best) { best = v; bi = e; }
     }
 #pragma unroll
@@ -399,10 +724,10 @@ __global__ void __launch_bounds__(64) k_brightest(const uint8_t *__restrict__ in
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
     if (lane == 0) {
-        const uint8_t *p = img + ((size_t)(r.y0 + bi / r.cols) * W + r.x0 + bi % r.cols) * 3;
+        const uint8_t *p = img + ((size_t)(k.y0 + bi / k.cols) * W + k.x0 + bi % k.cols) * 3;
         A[b * 3 + 0] = px_val(p[0], false);
-        A[b * 3 + 1] = px_val(p[1], px_atten(k, 1));
-        A[b * 3 + 2] = px_val(p[2], px_atten(k, 2));
+        A[b * 3 + 1] = px_val(p[1], px_atten(knd, 1));
+        A[b * 3 + 2] = px_val(p[2], px_atten(knd, 2));
     }
 }
 
@@ -470,8 +795,14 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
     UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(L.edges, 0, sizeof(uint32_t) * nreg, st));
-    for (int level = 0; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
+    static const bool use_tail = [] {
+        const char *e = getenv("UWIE_Q_TAIL");
+        return !(e && e[0] == '0');
+    }();
+    int level = 0;
+    for (; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
+        if (use_tail && (long long)qr * qc <= kNpChunk) break;  // k_q_tail walks the rest
         const int nch = cdiv((long long)qr * qc, kNpChunk);
         // sums -> squared deviations (means derived in the kernel) -> Canny -> select (totals derived in the kernel)
         UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
@@ -488,7 +819,14 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
         rmax = qr;
         cmax = qc;
     }
-    UWIE_LAUNCH(k_brightest, dim3(B), dim3(64), 0, st, d_in, d_kind, L.blk, s.H, s.W, d_A);
+    // the remaining levels (none when the walk above already reached the leaves) and the leaf's brightest pixel
+    static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(k_q_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4 * kTailQuadBytes) == hipSuccess;
+    }();
+    UWIE_REQUIRE(attr_set, "airlight: LDS request refused");
+    UWIE_LAUNCH(k_q_tail, dim3(B), dim3(256 * kTailSub), 4 * kTailQuadBytes, st, d_in, d_kind, d_gray, L.blk, s.H, s.W, level, min_size,
+                (TraceRec *)d_trace, d_A);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -12,24 +12,37 @@ constexpr int kNpChunk = 8192;     // NumPy's reduction buffer size
 constexpr int kMaxLeaves = 192;    // a leaf of the pairwise recursion holds 64..128 elements: at most 127 per chunk
 constexpr int kTreeLevels = 10;    // depth of that recursion for n < 8192 is at most 8
 
-template <class T>
+// LEAVES / LEVELS: 127 leaves and 7 levels are the most a chunk (< 8192 elements) needs; the defaults are generous
+template <class T, int LEAVES = kMaxLeaves, int LEVELS = kTreeLevels>
 struct PairwiseTreeT {  // LDS scratch of one wavefront
-    uint16_t off[kTreeLevels + 1][kMaxLeaves], len[kTreeLevels + 1][kMaxLeaves], child[kTreeLevels][kMaxLeaves];
-    int cnt[kTreeLevels + 1];
-    T val[2][3][kMaxLeaves];
+    uint16_t off[LEVELS + 1][LEAVES], len[LEVELS + 1][LEAVES], child[LEVELS][LEAVES];
+    int cnt[LEVELS + 1];
+    T val[2][3][LEAVES];
 };
 using PairwiseTree = PairwiseTreeT<float>;  // float32 data (the u8-derived frame); float64 images use PairwiseTreeT<double>
 
-// Three sums at once over a ragged chunk of `len` < 8192 elements, one wavefront (blockDim.x == 64, all lanes call).
-// The tree is expanded level by level with every lane working (a node list per level, kept in left-to-right order: a
-// split node is replaced by its two children in place), leaves are summed one per lane by `leaf(off, len, out3)`, and
-// the sums are folded back level by level (value = left + right, as the recursion returns them).  Result in lane 0.
-template <class T, class Leaf>
-__device__ void pairwise_ragged(int len, int lane, PairwiseTreeT<T> &t, Leaf leaf, T res[3])
+// WAVE_SYNC: several wavefronts of one workgroup each walk their own tree (no workgroup barrier: the tree is private to
+// the wavefront and LDS executes a wavefront's accesses in order; only the compiler has to be told)
+template <bool WAVE_SYNC>
+__device__ __forceinline__ void pairwise_sync()
+{
+    if constexpr (WAVE_SYNC) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// Enumerates the recursion's nodes level by level; returns the level that holds only leaves (its off/len/cnt entries
+// describe them).  The caller then stores every leaf's sums into t.val[level & 1][c][leaf] and calls pairwise_combine.
+template <class T, int LEAVES, int LEVELS, bool WAVE_SYNC>
+__device__ int pairwise_build(int len, int lane, PairwiseTreeT<T, LEAVES, LEVELS> &t)
 {
     int nlev = 0;
     if (lane == 0) { t.off[0][0] = 0; t.len[0][0] = (uint16_t)len; t.cnt[0] = 1; }
-    __syncthreads();
+    pairwise_sync<WAVE_SYNC>();
     for (;;) {
         const int cnt = t.cnt[nlev];
         int carry = 0;
@@ -58,15 +71,15 @@ __device__ void pairwise_ragged(int len, int lane, PairwiseTreeT<T> &t, Leaf lea
         if (!any) break;  // level `nlev` holds only leaves
         if (lane == 0) t.cnt[nlev + 1] = carry;
         ++nlev;
-        __syncthreads();
+        pairwise_sync<WAVE_SYNC>();
     }
-    const int nLeaf = t.cnt[nlev];
-    for (int i = lane; i < nLeaf; i += 64) {
-        T s[3];
-        leaf(t.off[nlev][i], t.len[nlev][i], s);
-        t.val[nlev & 1][0][i] = s[0]; t.val[nlev & 1][1][i] = s[1]; t.val[nlev & 1][2][i] = s[2];
-    }
-    __syncthreads();
+    return nlev;
+}
+
+// Post-order combination of the leaf sums stored at level nlev; the caller synchronises between storing them and this.
+template <class T, int LEAVES, int LEVELS, bool WAVE_SYNC>
+__device__ void pairwise_combine(int nlev, int lane, PairwiseTreeT<T, LEAVES, LEVELS> &t, T res[3])
+{
     for (int lv = nlev - 1; lv >= 0; --lv) {
         const int cnt = t.cnt[lv];
         for (int i = lane; i < cnt; i += 64) {
@@ -78,9 +91,34 @@ __device__ void pairwise_ragged(int len, int lane, PairwiseTreeT<T> &t, Leaf lea
                 t.val[lv & 1][c][i] = split ? a + t.val[(lv + 1) & 1][c][ch + 1] : a;
             }
         }
-        __syncthreads();
+        pairwise_sync<WAVE_SYNC>();
     }
     res[0] = t.val[0][0][0]; res[1] = t.val[0][1][0]; res[2] = t.val[0][2][0];
+}
+
+// Three sums at once over a ragged chunk of `len` < 8192 elements, one wavefront (blockDim.x == 64, all lanes call).
+// The tree is expanded level by level with every lane working (a node list per level, kept in left-to-right order: a
+// split node is replaced by its two children in place), leaves are summed one per lane by `leaf(off, len, out3)`, and
+// the sums are folded back level by level (value = left + right, as the recursion returns them).  Result in lane 0.
+template <class T, class Leaf, int LEAVES = kMaxLeaves, int LEVELS = kTreeLevels, bool WAVE_SYNC = false>
+__device__ void pairwise_ragged(int len, int lane, PairwiseTreeT<T, LEAVES, LEVELS> &t, Leaf leaf, T res[3])
+{
+    const int nlev = pairwise_build<T, LEAVES, LEVELS, WAVE_SYNC>(len, lane, t);
+    const int nLeaf = t.cnt[nlev];
+    for (int i = lane; i < nLeaf; i += 64) {
+        T s[3];
+        leaf(t.off[nlev][i], t.len[nlev][i], s);
+        t.val[nlev & 1][0][i] = s[0]; t.val[nlev & 1][1][i] = s[1]; t.val[nlev & 1][2][i] = s[2];
+    }
+    pairwise_sync<WAVE_SYNC>();
+    pairwise_combine<T, LEAVES, LEVELS, WAVE_SYNC>(nlev, lane, t, res);
+}
+
+// the same with the tree private to the calling wavefront (several wavefronts of a workgroup, one tree each)
+template <class T, class Leaf, int LEAVES, int LEVELS>
+__device__ void pairwise_ragged_wave(int len, int lane, PairwiseTreeT<T, LEAVES, LEVELS> &t, Leaf leaf, T res[3])
+{
+    pairwise_ragged<T, Leaf, LEAVES, LEVELS, true>(len, lane, t, leaf, res);
 }
 
 template <class T>
