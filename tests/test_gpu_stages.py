@@ -404,6 +404,35 @@ def test_atmospheric_light_matches_oracle_trace(dev, orc, frames):
         same(A[0].cpu().numpy(), np.asarray(want_A))
 
 
+def test_quadtree_edge_counts_with_isolated_strong_pixels(dev, orc):
+    """The Canny pre-pass (k_canny_strong: 256-column strips, 32-row bands, region borders replicated) and k_q_tail's
+    in-LDS Canny may never lose an edge: flat frames with one bright pixel at strip / band / quadrant borders, compared
+    with the oracle's trace level by level (the edge term is the only thing that separates the quadrants' scores)."""
+    import torch
+
+    H, W = 300, 1100
+    spots = [(0, 0), (149, 549), (150, 550), (31, 255), (32, 256), (33, 257), (299, 1099), (75, 1098), (64, 511), (150, 0),
+             (0, 550), (299, 549)]
+    for i, (py, px) in enumerate(spots):
+        u8 = np.full((H, W, 3), 90, np.uint8)
+        u8[..., 1] = 120
+        u8[py, px] = 255
+        if i % 3 == 2:  # a second, weak-only neighbourhood elsewhere: must not count
+            u8[(py + 97) % H, (px + 301) % W] = 112
+        x = orc.normalise_u8(u8)
+        kind = orc.classify_cast(x)
+        xc = orc.correct_cast(x, kind)
+        trace = []
+        want_A = orc.atmospheric_light(xc, 1, trace=trace)
+        kk = torch.tensor([KINDS.index(kind)], dtype=torch.int32, device=dev.torch_device)
+        A, tr = dev.atmospheric_light(dev.tensor(u8[None]), kk, trace=True)
+        for lvl, (y0, x0, rows, cols, scores) in enumerate(trace):
+            rec = tr[0, lvl]
+            assert (rec["y0"], rec["x0"], rec["rows"], rec["cols"]) == (y0, x0, rows, cols), ((py, px), lvl)
+            same(rec["score"], np.array(scores, np.float64))
+        same(A[0].cpu().numpy(), np.asarray(want_A))
+
+
 # ------------------------------------------------------------------ vgg_16_UIE.DifferentiableEnhancement (N3)
 def test_diff_enhance_matches_reference_outputs_and_oracle(dev, orc):
     """uwie_diff_enhance_f32 against the real module's outputs (tests/golden/vgg_stages.npz) and the torch-CPU oracle:

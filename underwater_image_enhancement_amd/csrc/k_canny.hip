@@ -67,6 +67,104 @@ __device__ __forceinline__ v2s byte_pair(uint32_t lo, uint32_t hi)
     return as_v2s(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)I | ((uint32_t)J << 16)));
 }
 
+// ---- pre-pass: does the region hold a pixel whose gradient magnitude exceeds the high threshold? ---------------------
+// The tile kernel above spends its time waiting (a short-lived workgroup per 32 x 64 tile: one load round trip, one
+// barrier).  This one streams: a wavefront owns a strip of 256 columns (4 per lane) and walks a band of rows with the
+// separable row terms of three rows in registers; each row is one (unaligned) 8-byte load per lane -- the lane's four
+// pixels and their two horizontal neighbours -- eight rows in flight.  Sobel on packed 16-bit pairs as above.
+// At the region's left / right border the window is assembled from the row's clamped 8-byte load with per-lane byte
+// shifts (BORDER_REPLICATE on the quadrant); lanes beyond the region compute garbage that is masked at the end.
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+constexpr int kPreRows = 32;   // rows per band
+constexpr int kPreCols = 256;  // columns per strip
+
+struct PreRow { v2s hd0, hd1, hs0, hs1; };
+
+template <bool EDGE>
+__device__ __forceinline__ PreRow pre_row(uint64_t w, const uint32_t (&sh)[6])
+{
+    uint32_t lo, hi;  // bytes 0..3 and 4..5 of the window x-1 .. x+4
+    if constexpr (EDGE) {
+        uint32_t b[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = (uint32_t)(w >> sh[k]) & 0xffu;
+        lo = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        hi = b[4] | (b[5] << 8);
+    } else {
+        lo = (uint32_t)w;
+        hi = (uint32_t)(w >> 32);
+    }
+    const v2s A0 = byte_pair<0, 1>(lo, hi), A1 = byte_pair<2, 3>(lo, hi), A2 = byte_pair<4, 5>(lo, hi);
+    const v2s B0 = byte_pair<1, 2>(lo, hi), B1 = byte_pair<3, 4>(lo, hi);
+    PreRow r;
+    r.hd0 = A1 - A0; r.hd1 = A2 - A1;
+    r.hs0 = A0 + B0 + B0 + A1; r.hs1 = A1 + B1 + B1 + A2;
+    return r;
+}
+
+template <bool EDGE>
+__device__ void pre_band(const uint8_t *__restrict__ g, int W, const Region &r, int x, int y0, int y1, uint32_t &top0, uint32_t &top1)
+{
+    // the 8 bytes loaded per row start at column xb of the region; window byte k sits sh[k] bits into them
+    const int xb = EDGE ? min(max(x - 1, 0), r.cols - 8) : x - 1;
+    uint32_t sh[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sh[k] = EDGE ? 8u * (uint32_t)(min(max(x - 1 + k, 0), r.cols - 1) - xb) : 0u;
+    const uint8_t *base = g + (size_t)r.y0 * W + r.x0 + xb;
+    auto load = [&](int y) -> uint64_t {
+        return *reinterpret_cast<const u64_unaligned *>(base + (size_t)min(max(y, 0), r.rows - 1) * W);
+    };
+    PreRow a = pre_row<EDGE>(load(y0 - 1), sh), b = pre_row<EDGE>(load(y0), sh);
+    v2s m0 = {0, 0}, m1 = {0, 0};
+    for (int yb = y0; yb < y1; yb += 8) {
+        uint64_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = load(min(yb + i, y1 - 1) + 1);  // (past the band: the last row again, harmless)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const PreRow c = pre_row<EDGE>(w[i], sh);
+            if (yb + i < y1) {
+                const v2s dx0 = a.hd0 + b.hd0 + b.hd0 + c.hd0, dx1 = a.hd1 + b.hd1 + b.hd1 + c.hd1;
+                const v2s dy0 = c.hs0 - a.hs0, dy1 = c.hs1 - a.hs1;
+                m0 = __builtin_elementwise_max(m0, __builtin_elementwise_abs(dx0) + __builtin_elementwise_abs(dy0));
+                m1 = __builtin_elementwise_max(m1, __builtin_elementwise_abs(dx1) + __builtin_elementwise_abs(dy1));
+                a = b;
+                b = c;
+            }
+        }
+    }
+    union { v2s v; uint32_t u; } c0, c1;
+    c0.v = m0; c1.v = m1;
+    top0 = c0.u; top1 = c1.u;
+}
+
+__global__ void __launch_bounds__(256) k_canny_strong(const uint8_t *__restrict__ gray, const Region *__restrict__ regs, int H,
+                                                      int W, int strips, int high, uint32_t *__restrict__ strong)
+{
+    const Region r = regs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) * 4 + wv;
+    const int x0 = strip * kPreCols, y0 = band * kPreRows;
+    if (x0 >= r.cols || y0 >= r.rows) return;
+    if (__hip_atomic_load(strong + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // already known
+    if (r.cols < 8) {  // narrower than one load: leave it to the full pass
+        if (lane == 0) strong[blockIdx.y] = 1;
+        return;
+    }
+    const int y1 = min(y0 + kPreRows, r.rows), x = x0 + 4 * lane;
+    const uint8_t *g = gray + (size_t)r.img * H * W;
+    uint32_t t0, t1;
+    if (x0 >= 1 && x0 + kPreCols + 3 <= r.cols) pre_band<false>  // (the 8-byte loads reach 2 columns past the window)
+       (g, W, r, x, y0, y1, t0, t1);
+    else pre_band<true>(g, W, r, x, y0, y1, t0, t1);
+    // pixel j of the lane is column x + j; columns beyond the region do not count
+    const int m[4] = {(int)(t0 & 0xffffu), (int)(t0 >> 16), (int)(t1 & 0xffffu), (int)(t1 >> 16)};
+    bool hot = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hot = hot || (x + j < r.cols && m[j] > high);
+    if (__ballot(hot) && lane == 0) strong[blockIdx.y] = 1;
+}
+
 // lock-free union-find on tile-local indices in LDS (links point to the smaller index)
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *L, int i)
 {
@@ -549,7 +647,13 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     if (d_edges || nreg > s.B * 4 || (env_pre && atoi(env_pre) == 0)) bufs.strong = nullptr;
     if (bufs.strong) {
         UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
-        UWIE_LAUNCH(k_canny_gradnms<true>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+        if (max_cols >= 8) {  // the streaming pre-pass loads 8 bytes per row
+            const int strips = cdiv(max_cols, kPreCols), bandgroups = cdiv(cdiv(max_rows, kPreRows), 4);
+            UWIE_LAUNCH(k_canny_strong, dim3(strips * bandgroups, nreg), block, 0, st, d_gray, d_regions, s.H, s.W, strips, high,
+                        bufs.strong);
+        } else {
+            UWIE_LAUNCH(k_canny_gradnms<true>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+        }
         UWIE_LAUNCH_CHECK();
     }
     UWIE_LAUNCH(k_canny_gradnms<false>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
