@@ -26,7 +26,7 @@ t0 = (1.0 - 0.5 * (field * 0.9 + 0.05 * torch.rand((B, H, W), device="cuda", gen
 
 
 def run(env, exact=False, reps=5):
-    for kk in ("UWIE_GF_PIPE", "UWIE_GF_RING_FORCE", "UWIE_GF_SPLIT"):
+    for kk in ("UWIE_GF_PIPE", "UWIE_GF_RING_FORCE", "UWIE_GF_SPLIT", "UWIE_GF_XCD"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     t = dev.guided_filter(gray, t0, k, eps, exact=exact)
@@ -46,7 +46,8 @@ ref = ref[:nb].clone()
 print(f"{H}x{W} x{B} k={k} eps={eps}")
 print(f"  exact-order kernels      {ms_ref:8.3f} ms")
 for name, env in (("round-1 wave (f64)", {"UWIE_GF_PIPE": "0"}), ("pipe, f64 ring in LDS", {"UWIE_GF_RING_FORCE": "0", "UWIE_GF_SPLIT": "0"}),
-                  ("pipe, f64 split ring", {"UWIE_GF_RING_FORCE": "0"}), ("pipe, fx32 ring", {"UWIE_GF_RING_FORCE": "1"})):
+                  ("pipe, f64 split ring", {"UWIE_GF_RING_FORCE": "0"}),
+                  ("  ... launch order as is", {"UWIE_GF_RING_FORCE": "0", "UWIE_GF_XCD": "0"}), ("pipe, fx32 ring", {"UWIE_GF_RING_FORCE": "1"})):
     t, ms = run(env)
     err = (t[:nb] - ref).abs().max().item()
     gbs = B * H * W * 13 / ms / 1e6

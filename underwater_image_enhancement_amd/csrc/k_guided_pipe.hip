@@ -658,6 +658,7 @@ struct RawRing<0> {
 
 struct SplitGeom {
     int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
+    int xcd_fold;        // fold launch order so that an XCD's workgroups are neighbours (see k_guided_split)
 };
 
 // Interior blocks only: every raw row/column the band touches exists (no reflection), W even, band % RC == 0.  Then a
@@ -667,7 +668,7 @@ struct SplitGeom {
 // constant: b lives in registers, the LDS address of a is an immediate, and there is no slot arithmetic at all.
 template <int K, bool EDGE, typename TOut>
 __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, const float *__restrict__ t0, TOut *__restrict__ tout,
-                                           const SplitGeom &g, const PipeConsts &cs, char *lds)
+                                           const SplitGeom &g, const PipeConsts &cs, char *lds, int3 bid)
 {
     using C = PipeCfg<K>;
     static_assert(K & 1, "odd window widths only (the entering row is the row just computed)");
@@ -678,10 +679,10 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     constexpr double K2 = (double)(K * K);
     const int lane = threadIdx.x;
     const int H = g.H, W = g.W;
-    const int x_lo = (int)blockIdx.x * NV;
-    const int y_lo = g.y0 + (int)blockIdx.y * g.band;
+    const int x_lo = bid.x * NV;
+    const int y_lo = g.y0 + bid.y * g.band;
     const int r_lo = y_lo - a;
-    const size_t img = (size_t)blockIdx.z * H * W;
+    const size_t img = (size_t)bid.z * H * W;
     const uint32_t npx = (uint32_t)H * (uint32_t)W;
     const __amdgpu_buffer_rsrc_t rT = pipe_rsrc(t0 + img, npx * 4u), rG = pipe_rsrc(gray + img, npx),
                                  rO = pipe_rsrc(tout + img, npx * (uint32_t)sizeof(TOut));
@@ -948,10 +949,24 @@ k_guided_split(const uint8_t *__restrict__ gray, const float *__restrict__ t0, T
 {
     extern __shared__ double2 lds_raw[];
     char *lds = reinterpret_cast<char *>(lds_raw);
-    const int x_lo = (int)blockIdx.x * PipeCfg<K>::NV;
+    // Neighbouring strips share the cache lines their halos overlap in (a strip advances 100 columns, its rows start at
+    // arbitrary bytes).  Workgroups are dealt to the 8 XCDs round-robin in launch order, so launch order is folded here:
+    // the workgroups one XCD receives form one contiguous run of (strip, band, image) triples, strips fastest, and
+    // neighbours run at the same time behind the same L2.
+    int3 bid = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    if (g.xcd_fold) {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+        const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t xcd = lin & 7u, idx = lin >> 3, q = n >> 3, r = n & 7u;
+        const uint32_t log = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bid.x = (int)(log % gx);
+        bid.y = (int)((log / gx) % gy);
+        bid.z = (int)(log / (gx * gy));
+    }
+    const int x_lo = bid.x * PipeCfg<K>::NV;
     const bool edge = x_lo - 2 * PipeCfg<K>::a < 0 || x_lo - 2 * PipeCfg<K>::a + kPipeSlots > g.W;  // wave-uniform
-    if (edge) split_body<K, true, TOut>(gray, t0, tout, g, cs, lds);
-    else split_body<K, false, TOut>(gray, t0, tout, g, cs, lds);
+    if (edge) split_body<K, true, TOut>(gray, t0, tout, g, cs, lds, bid);
+    else split_body<K, false, TOut>(gray, t0, tout, g, cs, lds, bid);
 }
 
 template <int K, typename TOut>
@@ -960,7 +975,9 @@ int launch_split(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCo
 {
     using C = PipeCfg<K>;
     constexpr int lds = C::RC * (C::NL + 1) * 16 + (C::s1_doubles + C::s2_doubles) * 8;
-    SplitGeom g{s.H, s.W, y0, band};
+    const char *e_fold = getenv("UWIE_GF_XCD");  // (experiment knob, read per call)
+    const bool fold = !(e_fold && e_fold[0] == '0');
+    SplitGeom g{s.H, s.W, y0, band, fold ? 1 : 0};
     const int nstrips = cdiv(s.W, C::NV);
     {
         UWIE_PROF("k_guided_split", st);
