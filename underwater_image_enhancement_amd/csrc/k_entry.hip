@@ -17,6 +17,8 @@
 #include "common.h"
 #include "devutil.h"
 
+#include <type_traits>
+
 namespace uwie {
 
 constexpr int kChunkPx = 16384;  // pixels per histogram chunk
@@ -91,10 +93,13 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 // again (per -> per/64, last level: 4 pixels added one by one), and the scan resumes behind it with the row of the binade
 // s is in by then.
 template <int per>
-__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, uint2 *row)
+__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, uint2 *row, int *cached,
+                       long long px_after)
 {
+    // px_after: pixels of the buffer that follow pixel p0 + cnt - 1 (reads may run 2 bytes past a lane's last pixel)
     const int lane = threadIdx.x & 63;
     const int ln = max(0, min(per, cnt - lane * per));
+    const long long ahead = px_after + max(0, cnt - (lane + 1) * per);  // ... that follow this lane's run
     const uint8_t *run = chan + (size_t)(p0 + lane * per) * 3;
     int first = 0;
     while (first < kWave) {
@@ -102,11 +107,16 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
         if (s >= 0.25f) {
             const int e = (int)(__float_as_uint(s) >> 23) - 127;
             const int ei = min(e - kCastBinadeMin, kCastBinades - 1), ei1 = min(ei + 1, kCastBinades - 1);
-            __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < 256; k += 64) row[k] = make_uint2(tab->RT[k][ei], tab->RT[k][ei1]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the rows of binades e and e+1 stay in this level's LDS buffer until the accumulator leaves e (a binade is
+            // left ~24 times per channel, a drill happens for every tie as well: one global round trip less per drill)
+            if (*cached != ei) {
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < 256; k += 64) row[k] = make_uint2(tab->RT[k][ei], tab->RT[k][ei1]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                *cached = ei;
+            }
             uint64_t D[2] = {0, 0};
             uint32_t T[2] = {0, 0};
             auto add = [&](uint32_t u) {
@@ -117,18 +127,26 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
             if (lane >= first) {
                 int i = 0;
                 if constexpr (per >= 64) {
-                    // 16 pixels = 48 bytes = 12 (unaligned) dwords per step, all loads of a step in flight together
-                    for (; i + 17 <= ln; i += 16) {  // (the 12th dword reaches 2 bytes past pixel i+15: keep one pixel behind it)
-                        const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(run + (size_t)i * 3);
-                        uint32_t d[12];
+                    // 16 pixels = 48 bytes = 12 (unaligned) dwords; STEPS such groups per trip with all their loads in flight
+                    // together (the lookups below wait for memory once per trip: a run of 256 pixels is 4 trips, not 16).
+                    // The 12th dword of a group reaches up to 2 bytes past its last pixel: `ahead` pixels of the buffer
+                    // follow this lane's run, so only the buffer's very last group is left to the byte loop.
+                    auto steps = [&](auto n_c) {
+                        constexpr int STEPS = decltype(n_c)::value;
+                        for (; i + 16 * STEPS <= ln && (i + 16 * STEPS < ln || ahead > 0); i += 16 * STEPS) {
+                            const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(run + (size_t)i * 3);
+                            uint32_t d[12 * STEPS];
 #pragma unroll
-                        for (int q = 0; q < 12; ++q) d[q] = w[q];
+                            for (int q = 0; q < 12 * STEPS; ++q) d[q] = w[q];
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int byte = 3 * q;
-                            add((d[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                            for (int q = 0; q < 16 * STEPS; ++q) {
+                                const int byte = 3 * q;
+                                add((d[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                            }
                         }
-                    }
+                    };
+                    steps(std::integral_constant<int, 4>{});
+                    steps(std::integral_constant<int, 1>{});
                 }
                 for (; i < ln; ++i) add(run[(size_t)i * 3]);
             }
@@ -147,7 +165,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
                 if (L >= kWave) break;
                 const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));  // wavefront-uniform
                 if constexpr (per > 4) {
-                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256);
+                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
                 } else {
                     if (lane == 0)
                         for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
@@ -168,7 +186,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
         if (L >= kWave) break;
         const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));
         if constexpr (per > 4) {
-            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256);
+            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
         } else {
             if (lane == 0)
                 for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
@@ -192,6 +210,7 @@ __global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__
     const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
     float s = 0.0f;
     int c = 0;
+    int cached[3] = {-1, -1, -1};  // binade whose table rows each drill level's LDS buffer holds
     while (c < nchunk) {
         int L = 0;  // chunks passed in closed form
         if (s >= 0.25f) {
@@ -209,7 +228,9 @@ __global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__
             c += L;
             if (L == kWave || c >= nchunk) continue;
         }
-        s = drill<kRunPx>(chan, c * kChunkPx, min(kChunkPx, npx - c * kChunkPx), s, tab, &row[0][0]);
+        const int cpx = min(kChunkPx, npx - c * kChunkPx);
+        s = drill<kRunPx>(chan, c * kChunkPx, cpx, s, tab, &row[0][0], cached,
+                          (long long)(gridDim.y - 1 - b) * npx + (npx - c * kChunkPx - cpx));
         ++c;
     }
     if (lane == 0) sums[b * 3 + ch] = s;
