@@ -753,7 +753,11 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
                                                      uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags)
 {
     using K = typename Traits<V>::K;
-    __shared__ uint32_t h[2048], wsum[16], found[2];
+    // The first pass also copies the elements of the query's bin into LDS (a window's list holds the neighbouring bins
+    // too; a bin is ~1/2048 of the plane): if they fit, the remaining passes never touch the list again.
+    constexpr int kBuf = 49152 / (int)sizeof(V);
+    __shared__ uint32_t h[2048], wsum[16], found[2], s_nloc;
+    __shared__ V s_buf[kBuf];
     const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;  // grid (B*3, ranks)
     const LinState *s = st + bc;
     const uint32_t g = s->gid[q];
@@ -767,25 +771,50 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
     K prefix = 0;
     uint32_t r = s->rr[q];
     const uint32_t tb = s->qbin[q];
+    if (tid == 0) s_nloc = 0;
+    uint32_t nloc = 0;
+    bool local = false;
     for (int p = 0; p < Traits<V>::NPASS; ++p) {
         const int shift = Traits<V>::shift(p), bits = Traits<V>::bits(p), nbins = 1 << bits;
         for (int i = tid; i < nbins; i += 1024) h[i] = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < cnt; base += 4096) {  // four loads in flight per thread
-            V x[4];
+        if (!local) {
+            for (uint32_t base = 0; base < cnt; base += 8192) {  // eight loads in flight per thread
+                V x[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = base + u * 1024 + tid;
-                x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = base + u * 1024 + tid;
+                    x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const K key = Traits<V>::key(x[u]);
+                    const bool mine = lin_digit(x[u]) == tb;
+                    if (mine && (p == 0 || (key >> (shift + bits)) == prefix))
+                        atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
+                    if (p == 0) {  // wavefront-aggregated append
+                        const uint64_t m = __ballot(mine);
+                        if (m) {
+                            const int lane = tid & 63, leader = (int)__builtin_ctzll(m);
+                            uint32_t at = 0;
+                            if (lane == leader) at = atomicAdd(&s_nloc, (uint32_t)__popcll(m));
+                            at = __shfl(at, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                            if (mine && at < (uint32_t)kBuf) s_buf[at] = x[u];
+                        }
+                    }
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const K key = Traits<V>::key(x[u]);
-                if (lin_digit(x[u]) == tb && (p == 0 || (key >> (shift + bits)) == prefix))
-                    atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
+        } else {
+            for (uint32_t i = tid; i < nloc; i += 1024) {
+                const K key = Traits<V>::key(s_buf[i]);
+                if ((key >> (shift + bits)) == prefix) atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
             }
         }
         __syncthreads();
+        if (p == 0) {
+            nloc = s_nloc;
+            local = nloc <= (uint32_t)kBuf;
+        }
         uint32_t d, rr;
         block_find_digit(h, nbins, r, wsum, found, d, rr);  // (threads 256.. hold no bins there)
         prefix = (prefix << bits) | d;
