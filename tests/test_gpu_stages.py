@@ -204,13 +204,14 @@ def test_transmission_init_and_guided_filter(dev, orc, frames):
             assert tx.dtype == np.float64 and np.abs(tx - want_t).max() <= 5e-10, (name, ks, np.abs(tx - want_t).max())
 
 
-@pytest.mark.parametrize("shape,bands", [((260, 700), 2), ((181, 256), 1), ((333, 490), 3)])
+@pytest.mark.parametrize("shape,bands", [((260, 700), 2), ((181, 256), 1), ((333, 490), 3), ((64, 300), 1), ((75, 128), 2)])
 def test_split_ring_guided_filter(dev, orc, monkeypatch, shape, bands):
-    """The split-ring kernel (k = 15: a in LDS, b in registers, steady loop unrolled over the ring period) with the general
-    pipelined kernel on the rows above and below it.  Production takes it for large batches only (4K x 64: the full-size
-    tests and bench.py); here UWIE_GF_BANDS forces it on small frames so that the oracle comparison covers every part of
-    it: edge strips (reflected columns, mirrored a/b), interior strips, a ragged last strip, several bands, the border
-    rows.  Same tolerance as every float64 ring: 1e-11 absolute on t."""
+    """The split-ring kernel (k = 15: a in LDS, b in registers, steady loop unrolled over the ring period; every row: row
+    indices are reflected at the top and bottom borders, a last period that runs past the image stores nothing there).
+    Production takes it for large batches only (4K x 64: the full-size tests and bench.py); here UWIE_GF_BANDS forces it
+    on small frames so that the oracle comparison covers every part of it: edge strips (reflected columns, mirrored a/b),
+    interior strips, a ragged last strip, several bands (the last one shorter), heights that are no multiple of the ring
+    period, frames barely taller than four windows.  Same tolerance as every float64 ring: 1e-11 absolute on t."""
     H, W = shape
     rng = np.random.default_rng(H * 1000 + W)
     B = 2

@@ -931,7 +931,7 @@ int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *s
     int iy0 = 0, band = 0, nb = 0;
     const bool split = guided_split_plan(Shape{batch, H, W}, ksize, &iy0, &band, &nb);
     *split_row0 = split ? iy0 : 0;
-    *split_rows = split ? band * nb : 0;
+    *split_rows = split ? std::min(band * nb, H - iy0) : 0;
     return UWIE_OK;
 }
 

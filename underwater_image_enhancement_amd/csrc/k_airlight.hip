@@ -631,6 +631,9 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
         if (threadIdx.x < 4) s_strong[threadIdx.x] = 0;
         tail_stage(img + ((size_t)r.y0 * W + r.x0) * 3, (size_t)W * 3, r.rows, r.cols * 3, pix, ql, 64 * kTailSub);
         __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t ca = wall_clock64();
+#endif
         nlev = s_nlev[qd];
         float S[3], V[3];
         {
@@ -639,11 +642,17 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
             tail_leaves<false>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
         }
         __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t cb = wall_clock64();
+#endif
         if (sw == 0) {
             pairwise_combine<float, 128, 8, true>(nlev, lane, tree, S);
             if (lane < 3) s_sum[qd][lane] = S[lane];
         }
         __syncthreads();
+#ifdef UWIE_TAIL_PROF
+        const uint64_t cc = wall_clock64();
+#endif
         {
             Elem<true> el;
             el.img = nullptr; el.W = 0; el.kind = knd;
@@ -698,6 +707,9 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
 #ifdef UWIE_TAIL_PROF  // 100 MHz ticks: sums, gray load, Canny
             t.score[0] = (double)(c1 - c0); t.score[1] = (double)(c2 - c1); t.score[2] = (double)(c3 - c2);
             t.score[3] = (double)(clock64() - k0) / (double)(wall_clock64() - c0);  // shader clocks per 10 ns
+#ifdef UWIE_TAIL_PROF2  // the sums phase in detail: build + stage, leaves, combine, squared-deviation leaves
+            t.score[0] = (double)(ca - c0); t.score[1] = (double)(cb - ca); t.score[2] = (double)(cc - cb); t.score[3] = (double)(c1 - cc);
+#endif
 #endif
         }
         k = arg == 0   ? Region{b, k.y0, k.x0, mr, mc}

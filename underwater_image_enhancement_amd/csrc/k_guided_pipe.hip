@@ -722,9 +722,8 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         uint32_t gl[2];         // (SPLIT_RAW_G == 0) guide bytes of the leaving row
     };
     auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
-    auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t oo_g, In &in) {
+    auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t ol_g, uint32_t oo_g, In &in) {
 #if !SPLIT_RAW_G
-        const uint32_t ol_g = oe_g - (uint32_t)RC * pitch_g;
         if constexpr (!EDGE) in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
         else {
             in.gl[0] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[0], ol_g, 0);
@@ -755,7 +754,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     RawRing<RC> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
     auto prologue_row = [&](auto j_tag) {
         constexpr int J = decltype(j_tag)::value;
-        const uint32_t row = (uint32_t)(r_lo - a + J);
+        const uint32_t row = (uint32_t)pipe_reflect(r_lo - a + J, H);  // rows above / below the image: BORDER_REFLECT_101
         uint32_t tb[2], gq[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -807,7 +806,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     };
 
     // One step i: C(i-2) [not in the warm period], B(i-1) on ring slot S, A(i).
-    auto step = [&](auto warm_tag, auto slot_tag, const In &in, uint32_t orow) {
+    auto step = [&](auto warm_tag, auto slot_tag, const In &in, uint32_t orow, bool row_ok) {
         constexpr bool WARM = decltype(warm_tag)::value;
         constexpr int S = decltype(slot_tag)::value;
         char *ring_p = lds + a_ring + (uint32_t)(S * NLp * EB);
@@ -838,10 +837,11 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             for (int c = 0; c < 2; ++c) {
                 const double gd = (double)byte_of(in.go, c);
                 const double q = fmin(fmax(fma(oab[c].x * cs.kaI, gd, fma(oab[c].y, cs.kb, cs.b0)), 0.1), 1.0);
+                const uint32_t oq = row_ok ? ofs_q[c] : kNoStore;  // (a band's last period may run past the image)
                 if constexpr (std::is_same<TOut, double>::value)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q), rO, ofs_q[c], orow, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q), rO, oq, orow, 0);
                 else
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)q), rO, ofs_q[c], orow, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)q), rO, oq, orow, 0);
             }
         }
         // B: a = cov / (var + eps), b = mean_p - a * mean_I (six_stadigy.py:39-40)
@@ -906,40 +906,44 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     pipe_sync();
     stage_v1();
     pipe_sync();
-    int i = r_lo + 1;
-    uint32_t oe_t = (uint32_t)(i + Lb) * pitch_t, oe_g = (uint32_t)(i + Lb) * pitch_g;
-    uint32_t oo_g = (uint32_t)max(i - 2 - a, 0) * pitch_g;  // (unused before the first normal step: i - 2 - a = y_lo there)
-    auto advance_loads = [&]() { oe_t += pitch_t; oe_g += pitch_g; };
+    // Row counters (wavefront-uniform, scalar): every row index is reflected into the image on use, which is all the top
+    // and bottom borders need -- a/b "rows" above row 0 computed from reflected raw rows ARE the a/b rows cv2.boxFilter's
+    // BORDER_REFLECT_101 mirrors in (the window of virtual row -j reflects onto the window of row j), and likewise below.
+    const int i0 = r_lo + 1;
+    int re = i0 + Lb;       // entering raw row of the next load (the leaving guide row is re - RC)
+    int gr = i0 - a - 2;    // guide row that rides with the next load: the load issued at step i (the third load) serves
+                            // step i+2, whose C phase stores row i-a (unused before the first normal step)
+    int yo = y_lo;          // row the next normal step stores
+    auto issue = [&](In &fill) {
+        const uint32_t er = (uint32_t)pipe_reflect(re, H), lr = (uint32_t)pipe_reflect(re - RC, H);
+        const uint32_t og = (uint32_t)min(max(gr, 0), H - 1);
+        load_rows(er * pitch_t, er * pitch_g, lr * pitch_g, og * pitch_g, fill);
+        ++re;
+        ++gr;
+    };
     In b0, b1, b2;
-    load_rows(oe_t, oe_g, oo_g, b0);
-    advance_loads();
-    load_rows(oe_t, oe_g, oo_g, b1);
-    advance_loads();
-    // guide rows of C: step i stores row i-2-a; its byte comes with the loads issued two steps earlier.  The first normal
-    // step is i = r_lo+RC+1 (row y_lo), loaded at warm step n = RC-2.
-    uint32_t orow = (uint32_t)y_lo * pitch_o;
-    auto one = [&](auto warm_tag, auto slot_tag, In &fill, const In &use, uint32_t guide_row_ofs) {
-        load_rows(oe_t, oe_g, guide_row_ofs, fill);
-        step(warm_tag, slot_tag, use, orow);
-        advance_loads();
-        if constexpr (!decltype(warm_tag)::value) orow += pitch_o;
+    issue(b0);
+    issue(b1);
+    auto one = [&](auto warm_tag, auto slot_tag, In &fill, const In &use) {
+        issue(fill);
+        step(warm_tag, slot_tag, use, (uint32_t)yo * pitch_o, yo < H);
+        if constexpr (!decltype(warm_tag)::value) ++yo;
         __builtin_amdgcn_sched_barrier(0);  // one step's LDS reads are not stretched over its neighbours (VGPR budget)
     };
-    auto period = [&](auto warm_tag, uint32_t &gofs) {
+    auto period = [&](auto warm_tag) {
         auto triple = [&](auto base_tag) {
             constexpr int S0 = decltype(base_tag)::value;
-            one(warm_tag, IC<S0>{}, b2, b0, gofs); gofs += pitch_g;
-            one(warm_tag, IC<S0 + 1>{}, b0, b1, gofs); gofs += pitch_g;
-            one(warm_tag, IC<S0 + 2>{}, b1, b2, gofs); gofs += pitch_g;
+            one(warm_tag, IC<S0>{}, b2, b0);
+            one(warm_tag, IC<S0 + 1>{}, b0, b1);
+            one(warm_tag, IC<S0 + 2>{}, b1, b2);
         };
         [&]<int... Q>(std::integer_sequence<int, Q...>) { (triple(IC<3 * Q>{}), ...); }(std::make_integer_sequence<int, RC / 3>{});
     };
-    // the load issued at step i serves step i+2, whose C phase stores row i-a: guide offset (i - a) * pitch_g
-    uint32_t gofs = (uint32_t)max(i - a, 0) * pitch_g;
     // warm period: steps r_lo+1 .. r_lo+RC (slots 0 .. RC-1)
-    period(std::true_type{}, gofs);
-    // normal periods: band rows
-    for (int p = 0; p < g.band / RC; ++p) period(std::false_type{}, gofs);
+    period(std::true_type{});
+    // normal periods: the band's rows (the last band stops at the image's last row)
+    const int nper = (min(g.band, H - y_lo) + RC - 1) / RC;
+    for (int p = 0; p < nper; ++p) period(std::false_type{});
 }
 
 
@@ -1025,16 +1029,16 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
 
 }  // namespace
 
-// Rows [*iy0, *iy0 + *nb * *band) go to k_guided_split (float64 ring, k = 15, an even W, a job large enough to fill the
-// chip with long bands), the rest to the general kernel; false = the general kernel alone.
+// Rows [*iy0, min(H, *iy0 + *nb * *band)) go to k_guided_split (float64 ring, k = 15, an even W, a job large enough to fill
+// the chip with long bands): all of them since the kernel reflects row indices itself; false = the general kernel alone.
 bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb)
 {
     const char *env_split = getenv("UWIE_GF_SPLIT");
     if (k != 15 || (s.W & 1) || (env_split && atoi(env_split) == 0)) return false;
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || s.npx() >= ((size_t)1 << 27)) return false;
     using C = PipeCfg<15>;
-    *iy0 = 2 * C::a;                                            // first band: raw rows from y - 2a >= 0
-    const int periods = (s.H - C::K_ - 1 - *iy0) / C::RC;       // last band: raw rows up to y_hi + K <= H - 1
+    *iy0 = 0;  // every row: the kernel reflects row indices at the top and bottom borders
+    const int periods = cdiv(s.H, C::RC);
     if (periods < 4) return false;
     const long strips = (long)cdiv(s.W, C::NV) * s.B;
     const char *env_b = getenv("UWIE_GF_BANDS");
@@ -1046,8 +1050,9 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb)
         n = std::min(n, std::max(1, periods / 12));  // ... but at least 12 periods (180 rows) long
     }
     n = std::max(1, std::min(n, periods));
-    *band = C::RC * (periods / n);
-    *nb = n;
+    const int per_band = cdiv(periods, n);
+    *band = C::RC * per_band;
+    *nb = cdiv(periods, per_band);  // the last band may be shorter (it stops at the image's last row)
     // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
     return env_b || strips * n >= 1024;
 }
@@ -1086,27 +1091,12 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
         cs.kb = scale;
         cs.b0 = 0.0;
     }
-    // float64, k = 15: the split-ring kernel takes the rows whose windows touch neither the top nor the bottom image
-    // border (every strip), the general kernel the rows above and below.  UWIE_GF_SPLIT=0 (read per call) keeps one general launch.
+    // float64, k = 15: the split-ring kernel.  UWIE_GF_SPLIT=0 (read per call) keeps the general kernel.
     if (ring == 0) {
         int iy0, band, nb;
         if (guided_split_plan(s, k, &iy0, &band, &nb)) {
-            const int iy1 = iy0 + nb * band;
-            const int border[6] = {iy0, iy1, band, 0, 0, 0};  // rows [0, iy0) and [iy1, H) of every strip
-            // the border rows are independent of the interior (disjoint outputs): on the side stream, if there is one,
-            // their short, ragged launch runs beside the main kernel instead of after it
-            hipStream_t bst = st;
-            if (side) {
-                UWIE_HIP_CHECK(hipEventRecord(side->fork, st));
-                UWIE_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-                bst = side->stream;
-            }
-            UWIE_TRY_RC((launch_pipe<15, false, double>(d_gray, d_t0, s, cs, d_t, bst, border)));
+            (void)side;  // (no border launch any more: the split kernel covers the top and bottom rows as well)
             UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, st)));
-            if (side) {
-                UWIE_HIP_CHECK(hipEventRecord(side->join, side->stream));
-                UWIE_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
-            }
             *handled = 1;
             return UWIE_OK;
         }
