@@ -176,8 +176,7 @@ int six_cast(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, 
 int six_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Shape s, const uwie_params *p, const Pipe &P,
                  hipStream_t st)
 {
-    UWIE_TRY(launch_quant_gray(d_in, kind, P.gray, s, p->gray_shift, st));
-    return launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st);
+    return launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift);
 }
 
 // Strategies 1-3 from (kind, gray, A) on: transmission -> guided filter -> restore -> stretch -> CLAHE / white balance.
@@ -241,8 +240,7 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
 int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
                     float *d_out_f32, hipStream_t st, double *d_out_f64 = nullptr)
 {
-    UWIE_TRY(launch_quant_gray(d_in, nullptr, P.gray, s, p->gray_shift, st));
-    UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st));
+    UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift));
     UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, (float)p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
     UWIE_TRY(stage_guided(ctx, P, s, p, st));
     SelectPlan plan;
@@ -881,8 +879,7 @@ int uwie_atmospheric_light(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
     void *ws = c.take<char>(airlight_ws_bytes(s));
     UWIE_CHECK_WS(c.total());
     hipStream_t st = (hipStream_t)stream;
-    UWIE_TRY(launch_quant_gray(d_in, d_kind, gray, s, p->gray_shift, st));
-    return launch_airlight(ctx, d_in, d_kind, gray, s, p->min_size, d_A, d_trace, ws, st);
+    return launch_airlight(ctx, d_in, d_kind, gray, s, p->min_size, d_A, d_trace, ws, st, p->gray_shift);
 }
 
 int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const float *d_A, int batch, int H,

@@ -145,8 +145,9 @@ int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gra
 
 // k_airlight.hip
 size_t airlight_ws_bytes(Shape s);
-int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const uint8_t *d_gray, Shape s,
-                    int min_size, float *d_A, void *d_trace, void *ws, hipStream_t st);
+// make_gray_shift != 0: d_gray is written on the way (the level-0 sums pass or k_quant_gray) instead of read
+int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int min_size,
+                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift = 0);
 
 // k_canny.hip  (regions: device array of nreg Region; max_rows/max_cols bound every region)
 size_t canny_ws_bytes(Shape s);

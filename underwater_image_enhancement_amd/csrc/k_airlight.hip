@@ -80,26 +80,51 @@ struct Elem {
     }
 };
 
-// NumPy's pairwise_sum on a block of n <= 128 elements starting at raster element e0, three channels at once.
-template <bool VAR>
-__device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, float out[3])
+// Level 0 only (GRAY): the sums pass visits every pixel of the frame exactly once with its normalised, colour-corrected
+// value in hand, so it also writes the 8-bit gray plane -- gray = cvtColor((x*255).astype(u8), RGB2GRAY), six_stadigy.py:149,177
+// -- instead of a separate sweep over the frame (k_quant_gray: 1.6 GB read again at 4K x 64).
+struct GrayOut {
+    uint8_t *plane;  // gray plane of the image (nullptr: none)
+    int shift;       // RGB2GRAY fixed point (15 or 14)
+};
+__device__ __forceinline__ uint32_t gray_of(float v0, float v1, float v2, int shift)
 {
+    return gray_fixed(quant_u8(v0), quant_u8(v1), quant_u8(v2), shift);
+}
+
+// NumPy's pairwise_sum on a block of n <= 128 elements starting at raster element e0, three channels at once.
+template <bool VAR, bool GRAY = false>
+__device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, float out[3], GrayOut go = GrayOut{nullptr, 15})
+{
+    static_assert(!(VAR && GRAY), "the gray plane rides with the plain sums");
     int ly = e0 / r.cols, lx = e0 % r.cols;
     const uint8_t *p = el.img + ((size_t)(r.y0 + ly) * el.W + r.x0 + lx) * 3;
+    uint8_t *gp = GRAY ? go.plane + (size_t)(r.y0 + ly) * el.W + r.x0 + lx : nullptr;
     auto step = [&]() {
         ++lx;
         p += 3;
+        if (GRAY) ++gp;
         if (lx == r.cols) {
             lx = 0;
             p += (size_t)(el.W - r.cols) * 3;
+            if (GRAY) gp += el.W - r.cols;
         }
+    };
+    // the three values of the pixel at p (and its gray byte on the way)
+    auto px3 = [&](float &v0, float &v1, float &v2) {
+        v0 = el.get(p, 0);
+        v1 = el.get(p, 1);
+        v2 = el.get(p, 2);
+        if constexpr (GRAY) *gp = (uint8_t)gray_of(v0, v1, v2, go.shift);
     };
     if (n < 8) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int i = 0; i < n; ++i) {
-            a0 += el.get(p, 0);
-            a1 += el.get(p, 1);
-            a2 += el.get(p, 2);
+            float v0, v1, v2;
+            px3(v0, v1, v2);
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
             step();
         }
         out[0] = a0; out[1] = a1; out[2] = a2;
@@ -108,16 +133,18 @@ __device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, f
     float acc[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c][j] = el.get(p, c);
+        px3(acc[0][j], acc[1][j], acc[2][j]);
         step();
     }
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c][j] += el.get(p, c);
+            float v0, v1, v2;
+            px3(v0, v1, v2);
+            acc[0][j] += v0;
+            acc[1][j] += v1;
+            acc[2][j] += v2;
             step();
         }
     }
@@ -125,8 +152,11 @@ __device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, f
 #pragma unroll
     for (int c = 0; c < 3; ++c) res[c] = tree8(acc[c]);
     for (; i < n; ++i) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) res[c] += el.get(p, c);
+        float v0, v1, v2;
+        px3(v0, v1, v2);
+        res[0] += v0;
+        res[1] += v1;
+        res[2] += v2;
         step();
     }
     out[0] = res[0]; out[1] = res[1]; out[2] = res[2];
@@ -137,11 +167,15 @@ __device__ void leaf_sum3(const Elem<VAR> &el, const Region &r, int e0, int n, f
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint4 __attribute__((aligned(1))) u128_unaligned;
 
-template <bool VAR>
-__device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, float out[3])
+typedef uint2 __attribute__((aligned(1))) u64x_unaligned;
+
+template <bool VAR, bool GRAY = false>
+__device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, float out[3], GrayOut go = GrayOut{nullptr, 15})
 {
+    static_assert(!(VAR && GRAY), "the gray plane rides with the plain sums");
     int ly = e0 / r.cols, lx = e0 % r.cols;
     const uint8_t *p = el.img + ((size_t)(r.y0 + ly) * el.W + r.x0 + lx) * 3;
+    uint8_t *gp = GRAY ? go.plane + (size_t)(r.y0 + ly) * el.W + r.x0 + lx : nullptr;
     float acc[3][8];
     if (lx + 128 <= r.cols) {
         // The leaf lies in one row: its 384 bytes come in as 24 (unaligned) 16-byte loads issued back to back; walking it
@@ -155,15 +189,21 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
         }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
+            uint32_t g8[2] = {0, 0};  // gray bytes of the step's eight pixels
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
+                float v3[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int byte = 24 * it + 3 * j + c;
                     const uint8_t u = (uint8_t)(raw[byte >> 2] >> (8 * (byte & 3)));
                     const float v = el.get(&u, 0, c);
+                    v3[c] = v;
                     acc[c][j] = it == 0 ? v : acc[c][j] + v;
                 }
+                if constexpr (GRAY) g8[j >> 2] |= gray_of(v3[0], v3[1], v3[2], go.shift) << (8 * (j & 3));
+            }
+            if constexpr (GRAY) *reinterpret_cast<u64x_unaligned *>(gp + 8 * it) = make_uint2(g8[0], g8[1]);
         }
         out[0] = tree8(acc[0]);
         out[1] = tree8(acc[1]);
@@ -172,6 +212,7 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
     }
     for (int it = 0; it < 16; ++it) {
         uint8_t px[24];
+        uint8_t *gq[8] = {};  // (GRAY) where the step's eight gray bytes go
         if (lx + 8 <= r.cols) {
             const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(p);
 #pragma unroll
@@ -182,11 +223,18 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
                 px[4 * q + 2] = (uint8_t)(v >> 16);
                 px[4 * q + 3] = (uint8_t)(v >> 24);
             }
+            if (GRAY) gq[0] = gp;
             lx += 8;
             p += 24;
+            if (GRAY) gp += 8;
             if (lx == r.cols) {
                 lx = 0;
                 p += (size_t)(el.W - r.cols) * 3;
+                if (GRAY) gp += el.W - r.cols;
+            }
+            if (GRAY) {
+#pragma unroll
+                for (int j = 1; j < 8; ++j) gq[j] = gq[0] + j;
             }
         } else {
 #pragma unroll
@@ -194,21 +242,28 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
                 px[3 * j] = p[0];
                 px[3 * j + 1] = p[1];
                 px[3 * j + 2] = p[2];
+                if (GRAY) gq[j] = gp;
                 ++lx;
                 p += 3;
+                if (GRAY) ++gp;
                 if (lx == r.cols) {
                     lx = 0;
                     p += (size_t)(el.W - r.cols) * 3;
+                    if (GRAY) gp += el.W - r.cols;
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+            float v3[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = el.get(px + 3 * j, c);
+                v3[c] = v;
                 acc[c][j] = it == 0 ? v : acc[c][j] + v;
             }
+            if constexpr (GRAY) *gq[j] = (uint8_t)gray_of(v3[0], v3[1], v3[2], go.shift);
+        }
     }
     out[0] = tree8(acc[0]);
     out[1] = tree8(acc[1]);
@@ -218,11 +273,12 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
 // One wavefront per (chunk, region).  csum[(reg*maxChunks + chunk)*3 + c] = pairwise sum of that chunk.
 // VAR with csum_in != nullptr: the means come from the chunk sums of the previous pass (added sequentially by lanes 0..2,
 // as k_q_combine would), so the quadtree needs no combine launch between its two passes.
-template <bool VAR>
+template <bool VAR, bool GRAY = false>
 __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                      const Region *__restrict__ regs, const float *__restrict__ mean,
                                                      int H, int W, int maxChunks, float *__restrict__ csum,
-                                                     const float *__restrict__ csum_in = nullptr)
+                                                     const float *__restrict__ csum_in = nullptr,
+                                                     uint8_t *__restrict__ gray_out = nullptr, int gray_shift = 15)
 {
     const int reg = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
     const Region r = regs[reg];
@@ -259,11 +315,12 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
         }
     }
     float *out = csum + ((size_t)reg * maxChunks + ci) * 3;
+    const GrayOut go{GRAY ? gray_out + (size_t)r.img * H * W : nullptr, gray_shift};
 
     if (len == kNpChunk) {
         // balanced tree: 64 leaves of 128, lane = leaf, butterfly == recursive halving
         float s[3];
-        leaf_sum3_full<VAR>(el, r, c0 + lane * 128, s);
+        leaf_sum3_full<VAR, GRAY>(el, r, c0 + lane * 128, s, go);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             s[0] += __shfl_xor(s[0], o);
@@ -275,7 +332,7 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     }
     // ragged chunk: the recursion tree of NumPy's pairwise sum for this length (pairwise_tree.h)
     float res[3];
-    pairwise_ragged(len, lane, tree, [&](int off, int l, float *s3) { leaf_sum3<VAR>(el, r, c0 + off, l, s3); }, res);
+    pairwise_ragged(len, lane, tree, [&](int off, int l, float *s3) { leaf_sum3<VAR, GRAY>(el, r, c0 + off, l, s3, go); }, res);
     if (lane == 0) { out[0] = res[0]; out[1] = res[1]; out[2] = res[2]; }
 }
 
@@ -791,8 +848,10 @@ size_t airlight_ws_bytes(Shape s)
     return c.total() + canny_ws_bytes(s);
 }
 
-int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, const uint8_t *d_gray, Shape s,
-                    int min_size, float *d_A, void *d_trace, void *ws, hipStream_t st)
+// make_gray_shift != 0: d_gray is not filled yet; the level-0 sums pass writes it (GrayOut) when level 0 is a launched
+// level, k_quant_gray otherwise.  UWIE_Q_GRAY_FUSE=0 always takes k_quant_gray.
+int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int min_size,
+                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift)
 {
     (void)ctx;
     Carver c(ws);
@@ -811,17 +870,37 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, c
         const char *e = getenv("UWIE_Q_TAIL");
         return !(e && e[0] == '0');
     }();
+    static const bool fuse_gray = [] {
+        const char *e = getenv("UWIE_Q_GRAY_FUSE");
+        return !(e && e[0] == '0');
+    }();
+    bool gray_pending = make_gray_shift != 0;
+    {
+        const bool level0_launched = s.H > min_size && s.W > min_size &&
+                                     !(use_tail && (long long)((s.H + 1) / 2) * ((s.W + 1) / 2) <= kNpChunk);
+        if (gray_pending && !(fuse_gray && level0_launched)) {
+            const int rc = launch_quant_gray(d_in, d_kind, d_gray, s, make_gray_shift, st);
+            if (rc != UWIE_OK) return rc;
+            gray_pending = false;
+        }
+    }
     int level = 0;
     for (; level < kMaxLevels && rmax > min_size && cmax > min_size; ++level) {
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
         if (use_tail && (long long)qr * qc <= kNpChunk) break;  // k_q_tail walks the rest
         const int nch = cdiv((long long)qr * qc, kNpChunk);
         // sums -> squared deviations (means derived in the kernel) -> Canny -> select (totals derived in the kernel)
-        UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
-                           s.W, maxChunks, L.csum, (const float *)nullptr);
+        if (gray_pending) {  // level 0: its four quadrants are the whole frame
+            UWIE_LAUNCH((k_q_chunk_sums<false, true>), dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H, s.W,
+                        maxChunks, L.csum, (const float *)nullptr, d_gray, make_gray_shift);
+            gray_pending = false;
+        } else {
+            UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H, s.W,
+                        maxChunks, L.csum, (const float *)nullptr, (uint8_t *)nullptr, 15);
+        }
         UWIE_LAUNCH_CHECK();
         UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), sizeof(float) * 3 * nch, st, d_in, d_kind, L.regs, L.mean, s.H,
-                           s.W, maxChunks, L.csum_var, (const float *)L.csum);
+                           s.W, maxChunks, L.csum_var, (const float *)L.csum, (uint8_t *)nullptr, 15);
         UWIE_LAUNCH_CHECK();
         int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
         if (rc != UWIE_OK) return rc;
