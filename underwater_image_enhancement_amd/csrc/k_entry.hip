@@ -27,30 +27,36 @@ constexpr int kRunPx = 256;      // pixels per lane inside a drilled chunk (64 *
 __global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ in, uint32_t *__restrict__ hist,
                                                     int npx, int nchunk)
 {
-    // eight copies selected by lane & 7, rows padded by one word: neighbouring pixels mostly share their values, and equal
-    // values from different lanes of a wavefront would otherwise serialise on one LDS address (or one bank)
-    __shared__ uint32_t h[8][769];
-    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, w = tid & 7;
-    for (int i = tid; i < 8 * 769; i += 256) (&h[0][0])[i] = 0;
+    // Sixteen copies selected by lane & 15, rows padded by one word: neighbouring pixels mostly share their values, and equal
+    // values from different lanes of a wavefront would otherwise serialise on one LDS address (or one bank).  A chunk
+    // holds 16384 pixels, so 16-bit counters suffice: two bins share a word and the sixteen copies fit where eight did.
+    __shared__ uint32_t h[16][385];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, w = tid & 15;
+    for (int i = tid; i < 16 * 385; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     const uint8_t *img = in + (size_t)b * npx * 3;
     const int p0 = c * kChunkPx, p1 = min(npx, p0 + kChunkPx);
     const bool aligned = (npx & 3) == 0;
+    auto bump = [&](uint32_t bin) { atomicAdd(&h[w][bin >> 1], 1u << (16 * (bin & 1))); };
     for (int p = p0 + tid * 4; p < p1; p += 1024) {
         const int n = min(4, p1 - p);
         const Px4 v = load_px4(img + (size_t)p * 3, n, aligned);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n) {
-                atomicAdd(&h[w][v.r[i]], 1u);
-                atomicAdd(&h[w][256 + v.g[i]], 1u);
-                atomicAdd(&h[w][512 + v.b[i]], 1u);
+                bump(v.r[i]);
+                bump(256 + v.g[i]);
+                bump(512 + v.b[i]);
             }
     }
     __syncthreads();
     uint32_t *out = hist + ((size_t)b * nchunk + c) * 768;
-    for (int i = tid; i < 768; i += 256)
-        out[i] = ((h[0][i] + h[1][i]) + (h[2][i] + h[3][i])) + ((h[4][i] + h[5][i]) + (h[6][i] + h[7][i]));
+    for (int i = tid; i < 768; i += 256) {
+        uint32_t n = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n += (h[k][i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        out[i] = n;
+    }
 }
 
 __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
