@@ -324,6 +324,7 @@ def main():
                     help="local: every rank enhances frames it already holds (headline, weak scaling).  scatter: rank 0 holds the "
                          "whole batch in HBM, each step = scatter over RCCL -> enhance -> gather (BASELINE.json configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel times of the recorded warm-up step to stderr")
     ap.add_argument("--no-extras", action="store_true", help="skip the other input distributions and the 1080p batch=1 case")
     args = ap.parse_args()
 
@@ -420,6 +421,9 @@ def main():
         bytes_launch = KERNEL_BYTES_PER_PX.get(name, 0) * cover * px_step / launches_per_step
         achieved = bytes_launch / (per_launch_ms * 1e-3) / 1e9
         kernel_ms = sum(v[0] for v in table.values())  # all kernels, from the recorded warm-up step
+        if args.kernel_table:
+            for kname, (kms, kcalls) in sorted(table.items(), key=lambda kv: -kv[1][0]):
+                print(f"  {kms:8.3f} ms  {kcalls:4d} launches  {kname}", file=sys.stderr)
         result = {
             "metric": "megapixels/sec enhanced", "value": round(value, 2), "unit": "megapixels/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

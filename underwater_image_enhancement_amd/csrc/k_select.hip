@@ -745,20 +745,23 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     flush(true);
 }
 
-// one block of 1024 per (image, channel, query): the query is finished on its list by a radix select (3 digits of the
-// float32 key, 6 of the float64 key) among the list's elements of the query's bin (a window's list holds neighbouring
-// bins too)
+// One block of 1024 per (image, channel, query): the query is finished on its list by a radix select among the list's
+// elements of the query's bin (a window's list holds neighbouring bins too).
+// The elements of one linear bin span 1/2048 of [0, 1], so their keys share most of their high bits: fixed key digits
+// would put thousands of increments on a handful of LDS counters (same-address atomics serialise; that was 0.28 ms at
+// 4K x 64).  The first sweep therefore only copies the bin's elements into LDS (if they fit) and takes the minimum and
+// maximum key; the select then runs over the bits in which those two differ, eleven at a time from the top, where the
+// elements spread evenly.
 template <typename V>
 __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const V *__restrict__ lists,
                                                      uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags)
 {
     using K = typename Traits<V>::K;
-    // The first pass also copies the elements of the query's bin into LDS (a window's list holds the neighbouring bins
-    // too; a bin is ~1/2048 of the plane): if they fit, the remaining passes never touch the list again.
     constexpr int kBuf = 49152 / (int)sizeof(V);
     __shared__ uint32_t h[2048], wsum[16], found[2], s_nloc;
+    __shared__ unsigned long long s_kmin, s_kmax;
     __shared__ V s_buf[kBuf];
-    const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x;  // grid (B*3, ranks)
+    const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;  // grid (B*3, ranks)
     const LinState *s = st + bc;
     const uint32_t g = s->gid[q];
     if (g == kLinDone) return;  // block-uniform: answered by the scan
@@ -768,59 +771,88 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         return;
     }
     const V *L = lists + ((size_t)bc * kLinLists + g) * cap;
-    K prefix = 0;
     uint32_t r = s->rr[q];
     const uint32_t tb = s->qbin[q];
-    if (tid == 0) s_nloc = 0;
-    uint32_t nloc = 0;
-    bool local = false;
-    for (int p = 0; p < Traits<V>::NPASS; ++p) {
-        const int shift = Traits<V>::shift(p), bits = Traits<V>::bits(p), nbins = 1 << bits;
+    if (tid == 0) {
+        s_nloc = 0;
+        s_kmin = ~0ull;
+        s_kmax = 0ull;
+    }
+    __syncthreads();
+    {
+        unsigned long long kmin = ~0ull, kmax = 0ull;
+        for (uint32_t base = 0; base < cnt; base += 8192) {  // eight loads in flight per thread
+            V x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = base + u * 1024 + tid;
+                x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool mine = lin_digit(x[u]) == tb;
+                const uint64_t m = __ballot(mine);
+                if (m) {  // wavefront-aggregated append
+                    const int leader = (int)__builtin_ctzll(m);
+                    uint32_t at = 0;
+                    if (lane == leader) at = atomicAdd(&s_nloc, (uint32_t)__popcll(m));
+                    at = __shfl(at, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                    if (mine) {
+                        const unsigned long long key = (unsigned long long)Traits<V>::key(x[u]);
+                        kmin = key < kmin ? key : kmin;
+                        kmax = key > kmax ? key : kmax;
+                        if (at < (uint32_t)kBuf) s_buf[at] = x[u];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = shfl_u64(kmin, lane ^ o), b = shfl_u64(kmax, lane ^ o);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        if (lane == 0) {
+            atomicMin(&s_kmin, kmin);
+            atomicMax(&s_kmax, kmax);
+        }
+    }
+    __syncthreads();
+    const uint32_t nloc = s_nloc;
+    const bool local = nloc <= (uint32_t)kBuf;
+    const unsigned long long kmin = s_kmin, kmax = s_kmax;
+    int lo = kmin == kmax ? 0 : 64 - __clzll((long long)(kmin ^ kmax));  // the keys differ in their low `lo` bits only
+    unsigned long long prefix = lo >= 64 ? 0ull : kmin >> lo;
+    while (lo > 0) {  // block-uniform
+        const int bits = min(11, lo), shift = lo - bits, nbins = 1 << bits;
         for (int i = tid; i < nbins; i += 1024) h[i] = 0;
         __syncthreads();
-        if (!local) {
-            for (uint32_t base = 0; base < cnt; base += 8192) {  // eight loads in flight per thread
+        auto take = [&](V x, bool ok) {
+            const unsigned long long key = (unsigned long long)Traits<V>::key(x);
+            if (ok && (lo >= 64 || (key >> lo) == prefix)) atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
+        };
+        if (local) {
+            for (uint32_t i = tid; i < nloc; i += 1024) take(s_buf[i], true);
+        } else {
+            for (uint32_t base = 0; base < cnt; base += 8192) {
                 V x[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const uint32_t i = base + u * 1024 + tid;
-                    x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
+                    x[u] = i < cnt ? L[i] : (V)-1;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const K key = Traits<V>::key(x[u]);
-                    const bool mine = lin_digit(x[u]) == tb;
-                    if (mine && (p == 0 || (key >> (shift + bits)) == prefix))
-                        atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
-                    if (p == 0) {  // wavefront-aggregated append
-                        const uint64_t m = __ballot(mine);
-                        if (m) {
-                            const int lane = tid & 63, leader = (int)__builtin_ctzll(m);
-                            uint32_t at = 0;
-                            if (lane == leader) at = atomicAdd(&s_nloc, (uint32_t)__popcll(m));
-                            at = __shfl(at, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                            if (mine && at < (uint32_t)kBuf) s_buf[at] = x[u];
-                        }
-                    }
-                }
-            }
-        } else {
-            for (uint32_t i = tid; i < nloc; i += 1024) {
-                const K key = Traits<V>::key(s_buf[i]);
-                if ((key >> (shift + bits)) == prefix) atomicAdd(&h[(uint32_t)(key >> shift) & (uint32_t)(nbins - 1)], 1u);
+                for (int u = 0; u < 8; ++u) take(x[u], lin_digit(x[u]) == tb);
             }
         }
         __syncthreads();
-        if (p == 0) {
-            nloc = s_nloc;
-            local = nloc <= (uint32_t)kBuf;
-        }
         uint32_t d, rr;
         block_find_digit(h, nbins, r, wsum, found, d, rr);  // (threads 256.. hold no bins there)
         prefix = (prefix << bits) | d;
         r = rr;
+        lo = shift;
     }
-    if (tid == 0) os[bc * kMaxRanks + q] = Traits<V>::value(prefix);
+    if (tid == 0) os[bc * kMaxRanks + q] = Traits<V>::value((K)prefix);
 }
 
 struct LinBufs {
