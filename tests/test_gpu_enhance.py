@@ -44,6 +44,21 @@ def test_enhance_matches_oracle(uw, orc, strategy):
     assert diff == 0, f"strategy {strategy}: {diff} of {total} bytes differ by 1 LSB"
 
 
+def test_enhance_ragged_midsize(uw, orc):
+    """Frames large enough for the launched quadtree levels (level 0 writes the gray plane on the way: GrayOut in
+    k_airlight.hip) with sizes that put leaves across row ends and leave ragged chunks: the gray plane feeds the guided
+    filter everywhere, so the whole output checks it."""
+    rng = np.random.default_rng(77)
+    for H, W in ((333, 517), (203, 1001)):
+        yy, xx = np.mgrid[0:H, 0:W]
+        field = 0.5 + 0.3 * np.sin(xx / 37.0) * np.cos(yy / 23.0)
+        f = field[:, :, None] * np.array([0.5, 0.8, 0.9]) + rng.normal(0, 0.03, (H, W, 3))
+        u8 = np.clip(np.floor(255 * f), 0, 255).astype(np.uint8)
+        u8[H // 3: H // 3 + 40, W // 4: W // 4 + 60] = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)  # a textured patch
+        for strategy in (2, 3):
+            assert check_u8(uw.enhance(u8, strategy=strategy), orc.enhance_u8(u8, strategy), f"{H}x{W} strategy {strategy}") == 0
+
+
 def test_enhance_640x480_canonical(uw, orc):
     rng = np.random.default_rng(1000)
     yy, xx = np.mgrid[0:480, 0:640]
