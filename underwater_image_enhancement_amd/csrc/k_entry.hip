@@ -69,25 +69,45 @@ __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
 // then depends on the parity of the running sum and the chunk has to be walked).  One thread per (channel, binade).
 constexpr uint64_t kTieBit = 1ull << 63;
 
+constexpr int kUlpChunks = 4;  // chunks per block: a table entry is fetched once for all of them
+
 __global__ void __launch_bounds__(128) k_chunk_ulps(const uint32_t *__restrict__ hist, const CastTables *__restrict__ tab,
                                                     int nchunk, uint64_t *__restrict__ ulps)
 {
-    __shared__ uint32_t h[768];
-    const size_t chunk = (size_t)blockIdx.y * nchunk + blockIdx.x;
-    for (int i = threadIdx.x; i < 768; i += 128) h[i] = hist[chunk * 768 + i];
+    __shared__ __attribute__((aligned(16))) uint32_t h[kUlpChunks][768];
+    const int c0 = blockIdx.x * kUlpChunks, nc = min(kUlpChunks, nchunk - c0);
+    const size_t chunk0 = (size_t)blockIdx.y * nchunk + c0;
+    for (int i = threadIdx.x; i < kUlpChunks * 768; i += 128) {
+        const int j = i / 768;
+        (&h[0][0])[i] = j < nc ? hist[chunk0 * 768 + i] : 0u;
+    }
     __syncthreads();
     const int t = threadIdx.x;
     if (t >= 3 * kCastBinades) return;
     const int ch = t / kCastBinades, ei = t - ch * kCastBinades;
-    uint64_t D = 0;
-    uint32_t tie = 0;
-#pragma unroll 8
-    for (int k = 0; k < 256; ++k) {
-        const uint32_t n = h[ch * 256 + k], rt = tab->RT[k][ei];  // threads of one channel read one 136-byte row
-        D += (uint64_t)n * (rt & 0x7fffffffu);
-        tie |= n ? rt >> 31 : 0u;
+    uint64_t D[kUlpChunks] = {};
+    uint32_t tie[kUlpChunks] = {};  // number of pixels whose value ties in this binade (only its being zero matters)
+#pragma unroll 2
+    for (int k = 0; k < 256; k += 4) {
+        uint32_t rv[4], tb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t rt = tab->RT[k + q][ei];  // threads of one channel read one 136-byte row
+            rv[q] = rt & 0x7fffffffu;
+            tb[q] = rt >> 31;
+        }
+#pragma unroll
+        for (int j = 0; j < kUlpChunks; ++j) {
+            const uint4 n4 = *reinterpret_cast<const uint4 *>(&h[j][ch * 256 + k]);
+            const uint32_t n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                D[j] += (uint64_t)n[q] * rv[q];
+                tie[j] = __umul24(n[q], tb[q]) + tie[j];  // n <= 16384
+            }
+        }
     }
-    ulps[(chunk * 3 + ch) * kCastBinades + ei] = D | (tie ? kTieBit : 0);
+    for (int j = 0; j < nc; ++j) ulps[((chunk0 + j) * 3 + ch) * kCastBinades + ei] = D[j] | (tie[j] ? kTieBit : 0);
 }
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -284,7 +304,7 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     float *sums = c.take<float>((size_t)s.B * 3);
     UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, hist, npx, nchunk);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_chunk_ulps, dim3(nchunk, s.B), dim3(128), 0, st, hist, ctx->d_cast, nchunk, ulps);
+    UWIE_LAUNCH(k_chunk_ulps, dim3(cdiv(nchunk, kUlpChunks), s.B), dim3(128), 0, st, hist, ctx->d_cast, nchunk, ulps);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, ulps, ctx->d_cast, npx, nchunk, sums);
     UWIE_LAUNCH_CHECK();
