@@ -126,26 +126,11 @@ uwie_params merged_params(const uwie_params *ps, int n, Shape s)
 int stage_guided(uwie_ctx *ctx, const Pipe &P, Shape s, const uwie_params *p, hipStream_t st)
 {
     int handled = 0;
-    // Side stream for the border rows: opt-in (UWIE_GF_SIDE=1, read per call).  Measured at 4K x 64: 13.70 ms per step
-    // with the border launch beside the main kernel vs 13.52 ms behind it -- the fork / join events and the contention
-    // cost more than the 0.3 ms launch they hide.  Never when the batch is split over the helper streams (they would share it).
-    SideStream side_s, *side = nullptr;
-    const char *env_streams = getenv("UWIE_STREAMS"), *env_side = getenv("UWIE_GF_SIDE");
-    if (ctx && !(env_streams && atoi(env_streams) > 1) && env_side && atoi(env_side) == 1) {
-        if (!ctx->side_ready) {
-            UWIE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-            UWIE_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-            UWIE_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-            ctx->side_ready = true;
-        }
-        side_s = SideStream{ctx->side, ctx->side_fork, ctx->side_join};
-        side = &side_s;
-    }
     // fixed-point a/b ring: only with the pre-clipped transmission of the six_stadigy surface (0.1 <= t0 <= 1 bounds a, b).
     // UWIE_GF_RING=1 (read per call, experiments) forces it like inter_dtype = UWIE_INTER_FX32.
     const char *env_ring = getenv("UWIE_GF_RING");
     const bool fx = p->surface == UWIE_SURFACE_SIX && (p->inter_dtype == UWIE_INTER_FX32 || (env_ring && atoi(env_ring) == 1));
-    if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, fx, side));
+    if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, fx));
     if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
     return UWIE_OK;
 }
@@ -459,7 +444,6 @@ int uwie_create(int device, uwie_ctx **out_ctx)
     UWIE_HIP_CHECK(hipSetDevice(device));
     uwie_ctx *ctx = new uwie_ctx();
     ctx->aux_ready = false;
-    ctx->side_ready = false;
     ctx->prof = prof_create();
     ctx->device = device;
     LabTables *lab = new LabTables();
@@ -492,11 +476,6 @@ void uwie_destroy(uwie_ctx *ctx)
             (void)hipEventDestroy(ctx->join[i]);
         }
         (void)hipEventDestroy(ctx->fork);
-    }
-    if (ctx->side_ready) {
-        (void)hipStreamDestroy(ctx->side);
-        (void)hipEventDestroy(ctx->side_fork);
-        (void)hipEventDestroy(ctx->side_join);
     }
     prof_bind(nullptr);
     prof_destroy(ctx->prof);

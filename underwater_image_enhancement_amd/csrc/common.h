@@ -90,10 +90,6 @@ struct uwie_ctx {
     hipStream_t aux[4];
     hipEvent_t fork, join[4];
     bool aux_ready;
-    // side stream for independent launches of one stage (the guided filter's border rows run beside its main kernel)
-    hipStream_t side;
-    hipEvent_t side_fork, side_join;
-    bool side_ready;
 };
 
 namespace uwie {
@@ -185,17 +181,12 @@ int launch_guided_wave(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
 bool guided_fast_handles(Shape s, int k);
 // k_guided_fast.hip: fused float64 guided filter (free summation order); *handled = 0 -> use launch_guided
 // ring_fx: the caller guarantees 0.1 <= t0 <= 1 (pre-clipped transmission) and accepts the fixed-point a/b ring
-// side != nullptr: a second stream with a fork and a join event; independent launches of the stage may run on it
-struct SideStream {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-};
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
-                       hipStream_t st, bool ring_fx = false, const SideStream *side = nullptr);
+                       hipStream_t st, bool ring_fx = false);
 // k_guided_pipe.hip: software-pipelined wavefront kernel for k in {10, 15, 20}; ring 0 = float64, 1 = fixed-point int32
 bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb);
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
-                       int *handled, hipStream_t st, const SideStream *side = nullptr);
+                       int *handled, hipStream_t st);
 
 // k_select.hip
 constexpr int kMaxPct = 4;  // percentiles per call

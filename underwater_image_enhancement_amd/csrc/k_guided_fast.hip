@@ -350,7 +350,7 @@ bool guided_fast_handles(Shape s, int k)
 // Returns UWIE_OK and sets *handled = 0 when the window is too wide for the LDS-resident formulation (the caller
 // then uses the exact-order path).
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
-                       hipStream_t st, bool ring_fx, const SideStream *side)
+                       hipStream_t st, bool ring_fx)
 {
     *handled = 0;
     // software-pipelined wavefront kernel (k_guided_pipe.hip) first; UWIE_GF_PIPE=0 keeps the round-1 kernels
@@ -358,7 +358,7 @@ int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
     if (!(env_pipe && atoi(env_pipe) == 0)) {
         const char *env_force = getenv("UWIE_GF_RING_FORCE");  // experiments only (profiles/gf_bench.py): 0 / 1
         if (env_force) ring_fx = atoi(env_force) == 1;
-        const int rcp = launch_guided_pipe(d_gray, d_t0, s, k, eps, ring_fx ? 1 : 0, d_t, handled, st, side);
+        const int rcp = launch_guided_pipe(d_gray, d_t0, s, k, eps, ring_fx ? 1 : 0, d_t, handled, st);
         if (rcp != UWIE_OK || *handled) return rcp;
     }
     static const char *no_wave = getenv("UWIE_GF_NO_WAVE");

@@ -1060,7 +1060,7 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb)
 // ring: 0 = float64 (split ring where guided_split_plan takes the job), 1 = fixed-point int32 (requires 0.1 <= t0 <= 1:
 // the caller's pre-clip, six_stadigy.py:174)
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
-                       int *handled, hipStream_t st, const SideStream *side)
+                       int *handled, hipStream_t st)
 {
     *handled = 0;
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || !(eps > 0.0)) return UWIE_OK;
@@ -1095,7 +1095,6 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
     if (ring == 0) {
         int iy0, band, nb;
         if (guided_split_plan(s, k, &iy0, &band, &nb)) {
-            (void)side;  // (no border launch any more: the split kernel covers the top and bottom rows as well)
             UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, st)));
             *handled = 1;
             return UWIE_OK;
