@@ -64,14 +64,19 @@ __global__ void k_make_quadrants(const Region *__restrict__ blk, Region *__restr
 template <bool VAR>
 struct Elem {
     const uint8_t *img;
-    int W, kind;
+    int W;
+    float att[3];  // color_correction's factor of the channel (six_stadigy.py:305-323): 0.85f or 1.0f (x * 1.0f == x)
     float mean[3];
+    __device__ __forceinline__ void set_kind(int kind)
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) att[c] = px_atten(kind, c) ? 0.85f : 1.0f;
+    }
     __device__ __forceinline__ float get(const uint8_t *p, int c) const { return get(p, c, c); }
     // value of byte p[i] taken as channel c
     __device__ __forceinline__ float get(const uint8_t *p, int i, int c) const
     {
-        float v = px_norm_fast(p[i]);
-        if (px_atten(kind, c)) v = v * 0.85f;
+        float v = px_norm_fast(p[i]) * att[c];  // (a multiply instead of a select per element)
         if (VAR) {
             const float d = v - mean[c];
             v = d * d;
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     Elem<VAR> el;
     el.img = in + (size_t)r.img * H * W * 3;
     el.W = W;
-    el.kind = kind ? kind[r.img] : 0;
+    el.set_kind(kind ? kind[r.img] : 0);
     if (VAR) {
         if (csum_in) {
             // the chunk sums come into LDS with coalesced loads; lanes 0..2 then add them in order
@@ -695,7 +700,7 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
         float S[3], V[3];
         {
             Elem<false> el;
-            el.img = nullptr; el.W = 0; el.kind = knd;
+            el.img = nullptr; el.W = 0; el.set_kind(knd);
             tail_leaves<false>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
         }
         __syncthreads();
@@ -712,7 +717,7 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
 #endif
         {
             Elem<true> el;
-            el.img = nullptr; el.W = 0; el.kind = knd;
+            el.img = nullptr; el.W = 0; el.set_kind(knd);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 S[c] = s_sum[qd][c];
