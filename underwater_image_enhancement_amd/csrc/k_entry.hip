@@ -171,6 +171,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
                             }
                         }
                     };
+                    steps(std::integral_constant<int, 16>{});
                     steps(std::integral_constant<int, 4>{});
                     steps(std::integral_constant<int, 1>{});
                 }
