@@ -112,6 +112,15 @@ __global__ void __launch_bounds__(128) k_chunk_ulps(const uint32_t *__restrict__
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
+// s + x[q0] + x[q0+1] + ... (qn <= 4 pixels, one after the other like NumPy): the lanes fetch the pixels side by side (one
+// memory round trip instead of qn), every lane then adds them in order.
+__device__ __forceinline__ float add_in_order(const uint8_t *__restrict__ chan, int q0, int qn, float s, int lane)
+{
+    const float x = lane < qn ? px_norm_fast(chan[(size_t)(q0 + lane) * 3]) : 0.0f;
+    for (int i = 0; i < qn; ++i) s = s + __shfl(x, i);
+    return s;
+}
+
 // Advance the accumulator `s` over pixels [p0, p0+cnt) of one channel (stride 3 bytes); all 64 lanes call.
 // Lanes take `per` consecutive pixels each.  One pass over the pixels gives every lane its ulp advance for the current
 // binade e AND for e+1 (the table rows of both sit in LDS), so the pixels are read once per call: a prefix scan finds the
@@ -119,7 +128,7 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 // again (per -> per/64, last level: 4 pixels added one by one), and the scan resumes behind it with the row of the binade
 // s is in by then.
 template <int per>
-__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, uint2 *row, int *cached,
+__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, ulonglong2 *row, int *cached,
                        long long px_after)
 {
     // px_after: pixels of the buffer that follow pixel p0 + cnt - 1 (reads may run 2 bytes past a lane's last pixel)
@@ -137,7 +146,13 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
             // left ~24 times per channel, a drill happens for every tie as well: one global round trip less per drill)
             if (*cached != ei) {
                 __builtin_amdgcn_wave_barrier();
-                for (int k = lane; k < 256; k += 64) row[k] = make_uint2(tab->RT[k][ei], tab->RT[k][ei1]);
+                // one 16-byte entry per byte value: the ulp count of binade e (and e+1) with its tie flag moved up to bit 40, so
+                // that one 64-bit add per binade and pixel accumulates both (256 counts below 2^26 stay below 2^34)
+                for (int k = lane; k < 256; k += 64) {
+                    const uint32_t r0 = tab->RT[k][ei], r1 = tab->RT[k][ei1];
+                    row[k] = make_ulonglong2((uint64_t)(r0 & 0x7fffffffu) | ((uint64_t)(r0 >> 31) << 40),
+                                             (uint64_t)(r1 & 0x7fffffffu) | ((uint64_t)(r1 >> 31) << 40));
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -146,9 +161,9 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
             uint64_t D[2] = {0, 0};
             uint32_t T[2] = {0, 0};
             auto add = [&](uint32_t u) {
-                const uint2 v = row[u];
-                D[0] += v.x & 0x7fffffffu; T[0] |= v.x >> 31;
-                D[1] += v.y & 0x7fffffffu; T[1] |= v.y >> 31;
+                const ulonglong2 v = row[u];
+                D[0] += v.x;
+                D[1] += v.y;
             };
             if (lane >= first) {
                 int i = 0;
@@ -177,6 +192,9 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
                 }
                 for (; i < ln; ++i) add(run[(size_t)i * 3]);
             }
+            // the tie counts rode above bit 40
+            T[0] = (uint32_t)(D[0] >> 40); T[1] = (uint32_t)(D[1] >> 40);
+            D[0] &= (1ull << 40) - 1; D[1] &= (1ull << 40) - 1;
             // events inside this pass: as long as s stays in e or e+1 the lane sums above remain valid
             for (;;) {
                 const int ec = (int)(__float_as_uint(s) >> 23) - 127;
@@ -194,9 +212,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
                 if constexpr (per > 4) {
                     s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
                 } else {
-                    if (lane == 0)
-                        for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
-                    s = __shfl(s, 0);
+                    s = add_in_order(chan, q0, qn, s, lane);
                 }
                 first = L + 1;
                 if (first >= kWave) break;
@@ -215,9 +231,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
         if constexpr (per > 4) {
             s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
         } else {
-            if (lane == 0)
-                for (int i = 0; i < qn; ++i) s = s + px_norm_fast(chan[(size_t)(q0 + i) * 3]);
-            s = __shfl(s, 0);
+            s = add_in_order(chan, q0, qn, s, lane);
         }
         first = L + 1;
     }
@@ -231,7 +245,7 @@ __global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__
                                                      const CastTables *__restrict__ tab, int npx, int nchunk,
                                                      float *__restrict__ sums)
 {
-    __shared__ uint2 row[2][256];  // table rows of the two binades in play, one set per drill level
+    __shared__ ulonglong2 row[2][256];  // table rows of the two binades in play, one set per drill level
     const int ch = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const uint8_t *chan = in + (size_t)b * npx * 3 + ch;
     const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
