@@ -405,6 +405,32 @@ def test_atmospheric_light_matches_oracle_trace(dev, orc, frames):
         same(A[0].cpu().numpy(), np.asarray(want_A))
 
 
+def test_atmospheric_light_other_leaf_sizes(dev, orc):
+    """min_size > 1 (the quadtree's leaf size, S6:49): the walk stops earlier -- inside the launched levels, at the hand-over
+    to k_q_tail, or inside it -- and the brightest pixel is taken over a larger leaf."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:300, 0:420]
+    f = (0.35 + 0.4 * np.exp(-((xx - 300) ** 2 + (yy - 90) ** 2) / 9000.0))[:, :, None] * np.array([0.5, 0.85, 0.9])
+    u8 = np.clip(255 * (f + rng.normal(0, 0.02, f.shape)), 0, 255).astype(np.uint8)
+    x = orc.normalise_u8(u8)
+    kind = orc.classify_cast(x)
+    xc = orc.correct_cast(x, kind)
+    kk = torch.tensor([KINDS.index(kind)], dtype=torch.int32, device=dev.torch_device)
+    for min_size in (2, 9, 40, 75, 150, 400):
+        p = dev.params(0, 2, min_size=min_size)
+        trace = []
+        want_A = orc.atmospheric_light(xc, min_size, trace=trace)
+        A, tr = dev.atmospheric_light(dev.tensor(u8[None]), kk, p=p, trace=True)
+        assert tr[0, len(trace)]["rows"] == 0, min_size
+        for lvl, (y0, x0, rows, cols, scores) in enumerate(trace):
+            rec = tr[0, lvl]
+            assert (rec["y0"], rec["x0"], rec["rows"], rec["cols"]) == (y0, x0, rows, cols), (min_size, lvl)
+            same(rec["score"], np.array(scores, np.float64))
+        same(A[0].cpu().numpy(), np.asarray(want_A))
+
+
 def test_quadtree_edge_counts_with_isolated_strong_pixels(dev, orc):
     """The Canny pre-pass (k_canny_strong: 256-column strips, 32-row bands, region borders replicated) and k_q_tail's
     in-LDS Canny may never lose an edge: flat frames with one bright pixel at strip / band / quadrant borders, compared
