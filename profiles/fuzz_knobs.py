@@ -24,15 +24,15 @@ for i in range(int(os.environ.get("N", "150"))):
         else:
             name = names[rng.integers(5)]
             x = orc.normalise_u8(u8)
-            # (float32 copies of the reference's float64 image: equal bit for bit without gamma, as in the tests)
-            want = ES.run(x, name, {}).astype(np.float32).view(np.uint32)
+            # the dict surface returns float64 like the reference: compared bit for bit (equal without gamma, as in the tests)
+            want = ES.run(x, name, {}).view(np.uint64)
             if os.environ.get("FUZZ_GF_EXACT") == "1":  # cv2.boxFilter's summation order: no tolerance on t left
                 from underwater_image_enhancement_amd import _lib
                 dev = uw.get_device(0)
                 p = dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], gf_exact=1, apply_gamma=0)
-                got = dev.enhance_u8(dev.tensor(u8[None]), p, want_float=True)[1][0].cpu().numpy().view(np.uint32)
+                got = dev.enhance_u8_f64(dev.tensor(u8[None]), p)[1][0].cpu().numpy().view(np.uint64)
             else:
-                got = uw.EnhancementStrategies.apply_strategy(x, name, {}).view(np.uint32)
+                got = np.ascontiguousarray(uw.EnhancementStrategies.apply_strategy(x, name, {})).view(np.uint64)
             what = name
     finally:
         for k in knobs: del os.environ[k]
