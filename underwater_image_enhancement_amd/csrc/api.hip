@@ -192,8 +192,13 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // 17.5 ms per step).
         const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call: the tests compare both modes
         recompute = k != 3 && !(env_store && atoi(env_store) == 1);
-        // (strategy 3 keeps the planes: its tail reads them; its four percentiles get four predicted windows)
-        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, &src));
+        // Strategy 3 keeps the planes (its tail reads them), so the exact target bins can be collected from them by one
+        // streaming sweep: no predicted windows there -- its percentiles (20 / 85 / 2 / 98) sit where the bins are full and
+        // four windows made the restore sweep 2.9 ms at 4K x 16 against 0.65 + 0.35 for sweep + collection.
+        // UWIE_LIN_PREDICT3=1 (read per call) brings the windows back.
+        const char *env_p3 = getenv("UWIE_LIN_PREDICT3");
+        const bool predict = k != 3 || (env_p3 && atoi(env_p3) == 1);
+        UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, predict ? &src : nullptr));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
                                             &plan));
         UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
