@@ -916,11 +916,17 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         cmax = qc;
     }
     // the remaining levels (none when the walk above already reached the leaves) and the leaf's brightest pixel
-    static const bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(k_q_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   4 * kTailQuadBytes) == hipSuccess;
-    }();
-    UWIE_REQUIRE(attr_set, "airlight: LDS request refused");
+    {
+        // more than 64 KB of LDS has to be asked for, once per device (a process may hold contexts on several)
+        static bool attr_set[64] = {};
+        int dev = 0;
+        UWIE_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_q_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               4 * kTailQuadBytes));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
     UWIE_LAUNCH(k_q_tail, dim3(B), dim3(256 * kTailSub), 4 * kTailQuadBytes, st, d_in, d_kind, d_gray, L.blk, s.H, s.W, level, min_size,
                 (TraceRec *)d_trace, d_A);
     UWIE_LAUNCH_CHECK();
