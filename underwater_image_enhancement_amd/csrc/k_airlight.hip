@@ -275,6 +275,25 @@ __device__ void leaf_sum3_full(const Elem<VAR> &el, const Region &r, int e0, flo
     out[2] = tree8(acc[2]);
 }
 
+// Sequential total of a region's chunk sums (NumPy adds each buffer's pairwise result into the running total): lanes 0..2
+// (one per channel) add src[k*3 + lane] for k = 0 .. nch-1 in order.  The sums come through a fixed-size LDS piece with
+// coalesced loads, so no launch has to size its LDS by the frame (a 24 MP still has 733 chunks per quadrant, 2^30 pixels
+// 32768).  One wavefront per workgroup.
+constexpr int kSumPiece = 256;
+__device__ __forceinline__ float seq_chunk_total(const float *__restrict__ src, int nch, int lane, float *piece)
+{
+    float acc = 0.0f;
+    for (int base = 0; base < nch; base += kSumPiece) {
+        const int m = min(kSumPiece, nch - base);
+        for (int i = lane; i < m * 3; i += 64) piece[i] = src[(size_t)base * 3 + i];
+        __syncthreads();
+        if (lane < 3)
+            for (int k = 0; k < m; ++k) acc = acc + piece[k * 3 + lane];
+        __syncthreads();
+    }
+    return acc;
+}
+
 // One wavefront per (chunk, region).  csum[(reg*maxChunks + chunk)*3 + c] = pairwise sum of that chunk.
 // VAR with csum_in != nullptr: the means come from the chunk sums of the previous pass (added sequentially by lanes 0..2,
 // as k_q_combine would), so the quadtree needs no combine launch between its two passes.
@@ -301,15 +320,10 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
     if (VAR) {
         if (csum_in) {
             // the chunk sums come into LDS with coalesced loads; lanes 0..2 then add them in order
-            extern __shared__ float cs_l[];
+            __shared__ float cs_l[kSumPiece * 3];
             const int nch = (n + kNpChunk - 1) / kNpChunk;
-            for (int i = lane; i < nch * 3; i += 64) cs_l[i] = csum_in[(size_t)reg * maxChunks * 3 + i];
-            __syncthreads();
-            float acc = 0.0f;
-            if (lane < 3) {
-                for (int k = 0; k < nch; ++k) acc = acc + cs_l[k * 3 + lane];
-                acc = (float)((double)acc / (double)n);  // numpy/_core/_methods.py:_mean
-            }
+            float acc = seq_chunk_total(csum_in + (size_t)reg * maxChunks * 3, nch, lane, cs_l);
+            if (lane < 3) acc = (float)((double)acc / (double)n);  // numpy/_core/_methods.py:_mean
             el.mean[0] = __shfl(acc, 0);
             el.mean[1] = __shfl(acc, 1);
             el.mean[2] = __shfl(acc, 2);
@@ -348,17 +362,14 @@ __global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ reg
                                                   int maxChunks, float *__restrict__ tot, float *__restrict__ mean)
 {
     // one wavefront per region: the chunk sums come into LDS with coalesced loads, lanes 0..2 then add them in order
-    extern __shared__ float cs[];
+    __shared__ float cs[kSumPiece * 3];
     const int reg = blockIdx.x, lane = threadIdx.x;
     const Region r = regs[reg];
     const int n = r.rows * r.cols;
     if (n == 0) return;
     const int nch = (n + kNpChunk - 1) / kNpChunk;
-    for (int i = lane; i < nch * 3; i += 64) cs[i] = csum[(size_t)reg * maxChunks * 3 + i];
-    __syncthreads();
+    const float acc = seq_chunk_total(csum + (size_t)reg * maxChunks * 3, nch, lane, cs);
     if (lane >= 3) return;
-    float acc = 0.0f;
-    for (int k = 0; k < nch; ++k) acc = acc + cs[k * 3 + lane];
     tot[reg * 3 + lane] = acc;
     if (!VAR) mean[reg * 3 + lane] = (float)((double)acc / (double)n);
 }
@@ -376,28 +387,33 @@ __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Regio
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (regs[b * 4].rows == 0) return;  // leaf reached earlier
-    extern __shared__ float cs_l[];  // [4 quadrants][2 passes][nchMax * 3]
-    int nchMax = 0;
+    // [4 quadrants][2 passes][kSumPiece * 3]: the chunk sums come through fixed-size pieces (coalesced loads), so the launch's
+    // LDS does not grow with the frame
+    __shared__ float cs_l[8][kSumPiece * 3];
+    int nchq[4], nchMax = 0;
     for (int q = 0; q < 4; ++q) {
         const Region r = regs[b * 4 + q];
-        nchMax = max(nchMax, (r.rows * r.cols + kNpChunk - 1) / kNpChunk);
+        nchq[q] = (r.rows * r.cols + kNpChunk - 1) / kNpChunk;
+        nchMax = max(nchMax, nchq[q]);
     }
-    for (int q = 0; q < 4; ++q) {
-        const Region r = regs[b * 4 + q];
-        const int nch = (r.rows * r.cols + kNpChunk - 1) / kNpChunk;
-        for (int i = lane; i < nch * 3; i += 64) {
-            cs_l[(q * 2 + 0) * nchMax * 3 + i] = csum[(size_t)(b * 4 + q) * maxChunks * 3 + i];
-            cs_l[(q * 2 + 1) * nchMax * 3 + i] = csum_var[(size_t)(b * 4 + q) * maxChunks * 3 + i];
-        }
-    }
-    __syncthreads();
     float acc = 0.0f;
-    if (lane < 24) {
-        const int q = lane / 6, pass = (lane % 6) / 3, c = lane % 3;
-        const Region r = regs[b * 4 + q];
-        const int n = r.rows * r.cols, nch = (n + kNpChunk - 1) / kNpChunk;
-        const float *cs = cs_l + (q * 2 + pass) * nchMax * 3 + c;
-        for (int k = 0; k < nch; ++k) acc = acc + cs[k * 3];
+    const int lq = lane < 24 ? lane / 6 : 0, lpass = (lane % 6) / 3, lc = lane % 3;
+    for (int base = 0; base < nchMax; base += kSumPiece) {
+        for (int q = 0; q < 4; ++q) {
+            const int m = min(kSumPiece, nchq[q] - base);
+            const size_t off = ((size_t)(b * 4 + q) * maxChunks + base) * 3;
+            for (int i = lane; i < m * 3; i += 64) {
+                cs_l[q * 2 + 0][i] = csum[off + i];
+                cs_l[q * 2 + 1][i] = csum_var[off + i];
+            }
+        }
+        __syncthreads();
+        if (lane < 24) {
+            const int m = min(kSumPiece, nchq[lq] - base);
+            const float *cs = cs_l[lq * 2 + lpass] + lc;
+            for (int k = 0; k < m; ++k) acc = acc + cs[k * 3];
+        }
+        __syncthreads();
     }
     float tots[24];
 #pragma unroll
@@ -836,12 +852,12 @@ int launch_region_stats(const uint8_t *d_in, const int32_t *d_kind, const Region
     UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum,
                 (const float *)nullptr);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, tot, mean);
+    UWIE_LAUNCH(k_q_combine<false>, dim3(nreg), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, tot, mean);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, d_regs, mean, s.H, s.W, maxChunks, csum,
                 (const float *)nullptr);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), sizeof(float) * 3 * nch, st, d_regs, csum, nreg, maxChunks, vtot, mean);
+    UWIE_LAUNCH(k_q_combine<true>, dim3(nreg), dim3(64), 0, st, d_regs, csum, nreg, maxChunks, vtot, mean);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -904,12 +920,12 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
                         maxChunks, L.csum, (const float *)nullptr, (uint8_t *)nullptr, 15);
         }
         UWIE_LAUNCH_CHECK();
-        UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), sizeof(float) * 3 * nch, st, d_in, d_kind, L.regs, L.mean, s.H,
+        UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
                            s.W, maxChunks, L.csum_var, (const float *)L.csum, (uint8_t *)nullptr, 15);
         UWIE_LAUNCH_CHECK();
         int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
         if (rc != UWIE_OK) return rc;
-        UWIE_LAUNCH(k_q_select, dim3(B), dim3(64), sizeof(float) * 24 * nch, st, L.blk, L.regs, (const float *)L.csum, (const float *)L.csum_var,
+        UWIE_LAUNCH(k_q_select, dim3(B), dim3(64), 0, st, L.blk, L.regs, (const float *)L.csum, (const float *)L.csum_var,
                            maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
