@@ -21,7 +21,9 @@ namespace {
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint4 __attribute__((aligned(1))) u128_unaligned;
 
-__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+// np.clip(v, 0, 1) for a value that is not NaN: one instruction (the clamp output modifier)
+__device__ __forceinline__ float clip01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
 #define UWIE_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
@@ -40,18 +42,23 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
 {
     constexpr int NB = LIN ? 2052 : 2048;
     constexpr bool F64 = sizeof(V) == 8;
+    // FAST (the float32 linear-digit sweep of strategies 1-3): whole 4-pixel groups take a straight-line path -- numerators
+    // from a float64 table in LDS, no range test on the divisor (t is the guided filter's output, clipped to [0.1, 1]), one
+    // saturation test per group instead of four operations per value (round 3: 102 -> ~60 VALU instructions per pixel)
+    constexpr bool FAST = LIN && !F64;
     constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 && !F64 ? 256 : 128) : 1;  // 6 KB of stages (12: float64, NW 4)
     __shared__ uint32_t h[3][NB];
     __shared__ V stg[NS][SN];
     __shared__ uint32_t scount[NS], sbase[NS];
+    __shared__ double dtab[FAST ? 768 : 1];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (only && !(only[3 * b] | only[3 * b + 1] | only[3 * b + 2])) return;
     if (ghist) {
         for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
         if (tid < NS) scount[tid] = 0;
     }
-    RestoreImgT<false> R;
-    R.init(S, b, (size_t)npx);
+    RestoreImgT<FAST ? 2 : 0> R;
+    R.init(S, b, (size_t)npx, dtab);
     __syncthreads();
     V *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
@@ -117,7 +124,64 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     for (int it = 0; it < iters; ++it) {
         const int p = it * step + (blockIdx.x * 256 + tid) * 4;
         const int n = min(4, npx - p);
-        if (n > 0) {
+        bool done = false;
+        if constexpr (FAST) {
+            if (n == 4 && ghist) {
+                done = true;
+                uint32_t w[3];
+                double tv[4];
+                R.load_four(p, w, tv);
+                float v[3][4];  // restored values before the clip
+                R.four_raw(w, tv, v);
+                // One saturation test per group: clipped zeros and ones fill whole regions (their bins would serialise the
+                // LDS atomics 64 deep), so a group that holds any takes the per-value route below; every other group's
+                // digit is (uint)(v * 2048) + 1 straight away.
+                const float lo = fminf(fminf(__builtin_fminf(v[0][0], __builtin_fminf(v[0][1], v[0][2])), __builtin_fminf(v[0][3], __builtin_fminf(v[1][0], v[1][1]))),
+                                       fminf(__builtin_fminf(v[1][2], __builtin_fminf(v[1][3], v[2][0])), __builtin_fminf(v[2][1], __builtin_fminf(v[2][2], v[2][3]))));
+                const float hi = fmaxf(fmaxf(__builtin_fmaxf(v[0][0], __builtin_fmaxf(v[0][1], v[0][2])), __builtin_fmaxf(v[0][3], __builtin_fmaxf(v[1][0], v[1][1]))),
+                                       fmaxf(__builtin_fmaxf(v[1][2], __builtin_fmaxf(v[1][3], v[2][0])), __builtin_fmaxf(v[2][1], __builtin_fmaxf(v[2][2], v[2][3]))));
+                uint32_t old[3][4];
+                if (lo > 0.0f && hi < 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) old[c][i] = atomicAdd(&h[c][1 + (uint32_t)(v[c][i] * 2048.0f)], 1u);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float x = v[c][i];
+                            const bool z = !(x > 0.0f), o = x >= 1.0f;
+                            sat0[c] += z;
+                            sat1[c] += o;
+                            old[c][i] = z || o ? 0u : atomicAdd(&h[c][1 + (uint32_t)(x * 2048.0f)], 1u);
+                            v[c][i] = z ? 0.0f : o ? 1.0f : x;
+                        }
+                }
+                if (COLLECT) {  // a candidate is never a clipped value: v is what it is
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            if (old[c][i] > kCntMask) file(c, (int)(old[c][i] >> kFlagShift) - 1, v[c][i]);
+                }
+                if (planar) {
+                    if (aligned) {
+                        *reinterpret_cast<float4 *>(o0 + p) = make_float4(clip01(v[0][0]), clip01(v[0][1]), clip01(v[0][2]), clip01(v[0][3]));
+                        *reinterpret_cast<float4 *>(o1 + p) = make_float4(clip01(v[1][0]), clip01(v[1][1]), clip01(v[1][2]), clip01(v[1][3]));
+                        *reinterpret_cast<float4 *>(o2 + p) = make_float4(clip01(v[2][0]), clip01(v[2][1]), clip01(v[2][2]), clip01(v[2][3]));
+                    } else {
+                        for (int i = 0; i < 4; ++i) {
+                            o0[p + i] = clip01(v[0][i]);
+                            o1[p + i] = clip01(v[1][i]);
+                            o2[p + i] = clip01(v[2][i]);
+                        }
+                    }
+                }
+            }
+        }
+        if (n > 0 && !done) {
             V r[3][4];
             if constexpr (F64) R.four64(p, n, r);
             else R.four(p, n, r);
@@ -230,6 +294,25 @@ struct Stretch {  // per image: lo and denominator per channel, for one or two c
         if (two) v = clip01(d2[c].quot_unit(v - lo2[c]));
         return v;
     }
+    // Single stretch with a divisor inside StretchDiv's fast range (allfast()): the four values of one channel as two
+    // packed float32 pairs (v_pk_add / v_pk_mul / v_pk_fma: the same operations in the same order, two lanes per
+    // instruction), then (x * 255).astype(u8) as an index.  v is the clipped restored value.
+    __device__ __forceinline__ bool allfast() const { return !two && d1[0].fast && d1[1].fast && d1[2].fast; }
+    __device__ __forceinline__ void codes4(const float (&v)[4], int c, uint32_t (&code)[4]) const
+    {
+        const float den = d1[c].den, y = d1[c].y, lo = lo1[c];
+        const f32x2 nd = {-den, -den}, yy = {y, y};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 n = f32x2{v[2 * h], v[2 * h + 1]} - lo;
+            f32x2 q = n * y;
+            q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, n), yy, q);
+            q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, n), yy, q);
+            const f32x2 s = f32x2{clip01(q.x), clip01(q.y)} * 255.0f;
+            code[2 * h] = (uint32_t)(int)s.x;
+            code[2 * h + 1] = (uint32_t)(int)s.y;
+        }
+    }
     // for results that are kept as float32
     __device__ __forceinline__ float apply_exact(float v, int c) const
     {
@@ -268,7 +351,7 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     __shared__ uint32_t wsum[4];
     __shared__ uint16_t s_gamma[256], s_cbrt[3072];
     __shared__ int s_fwd[9];
-    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, w4 = w;
     for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
     for (int i = tid; i < 256; i += 256) s_gamma[i] = T->gamma[i];
     for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
@@ -282,8 +365,8 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     const int npx = g.H * g.W;
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
     const uint8_t *img8 = src.in + (size_t)b * npx * 3;
-    __shared__ float dtab[SRC == 1 ? 768 : 1];
-    RestoreImgT<true> R;
+    __shared__ double dtab[SRC == 1 ? 768 : 1];
+    RestoreImgT<2> R;
     if (SRC == 1) {
         R.init(src, b, (size_t)npx, dtab);
         __syncthreads();
@@ -309,9 +392,61 @@ __global__ void __launch_bounds__(256) k_stretch_lab_lut(const LabTables *__rest
     const int x_lo = txi * g.tw, x_hi = min(x_lo + g.tw, g.W), y_lo = ty * g.th, y_hi = min(y_lo + g.th, g.H);
     const int gpr = max((x_hi - x_lo + 3) / 4, 0), total = max(y_hi - y_lo, 0) * gpr;
     const uint32_t gmagic = (uint32_t)(((1ull << 32) + max(gpr, 1) - 1) / max(gpr, 1));
+    // RGB2LAB of gamma-table values (OpenCV's RGB2Lab_b): the matrix comes from scalar registers, products of 12-bit
+    // values by 12-bit coefficients through the 24-bit multiplier
+    const int f0 = T->fwd[0], f1 = T->fwd[1], f2 = T->fwd[2], f3 = T->fwd[3], f4 = T->fwd[4], f5 = T->fwd[5], f6 = T->fwd[6],
+              f7 = T->fwd[7], f8 = T->fwd[8];
+    auto lab_of = [&](uint32_t Rg, uint32_t Gg, uint32_t Bg, uint32_t &L, uint32_t &a, uint32_t &bb) {
+        const uint32_t ix = (__umul24(Rg, f0) + __umul24(Gg, f1) + __umul24(Bg, f2) + 2048u) >> 12;
+        const uint32_t iy = (__umul24(Rg, f3) + __umul24(Gg, f4) + __umul24(Bg, f5) + 2048u) >> 12;
+        const uint32_t iz = (__umul24(Rg, f6) + __umul24(Gg, f7) + __umul24(Bg, f8) + 2048u) >> 12;
+        const int fX = s_cbrt[ix], fY = s_cbrt[iy], fZ = s_cbrt[iz];
+        // saturate_cast<uchar>(x >> 15) as clamp-then-shift: written shift-then-clamp, two adjacent values become one
+        // v_ashr_pk_u8_i32 (new on gfx950), whose result did not match on the hardware (round 3: a and b of every fourth
+        // pixel came out wrong); the clamp keeps x in [0, 2^23), so a logical shift finishes the job
+        auto sat15 = [](int x) { return (uint32_t)min(max(x, 0), (256 << 15) - 1) >> 15; };
+        L = sat15(__mul24(Lscale, fY) + (Lshift + (1 << 14)));
+        a = sat15(__mul24(500, fX - fY) + (128 * (1 << 15) + (1 << 14)));
+        bb = sat15(__mul24(200, fY - fZ) + (128 * (1 << 15) + (1 << 14)));
+    };
+    const bool fastpath = SRC == 1 && S.allfast();  // block-uniform
     for (int gi = tid; gi < total; gi += 256) {
         const int row = gpr == 1 ? gi : (int)__umulhi((uint32_t)gi, gmagic), xg = gi - row * gpr;  // gi / gpr
         const int x0 = x_lo + 4 * xg, n = min(4, x_hi - x0), p = (y_lo + row) * g.W + x0;
+        if (SRC == 1 && fastpath && n == 4) {
+            // whole groups of a recomputed image: straight-line restore (restore.h four_raw), packed stretch
+            uint32_t w[3];
+            double tv[4];
+            R.load_four(p, w, tv);
+            float v[3][4];
+            R.four_raw(w, tv, v);
+            uint32_t code[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float r[4] = {clip01(v[c][0]), clip01(v[c][1]), clip01(v[c][2]), clip01(v[c][3])};
+                S.codes4(r, c, code[c]);
+            }
+            uint32_t L[4], a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lab_of(s_gamma[code[0][i]], s_gamma[code[1][i]], s_gamma[code[2][i]], L[i], a[i], bb[i]);
+            uint32_t cl = L[0], cn = 1;  // runs of equal L inside the group: one LDS atomic per run
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                if (L[i] == cl) {
+                    ++cn;
+                } else {
+                    atomicAdd(&h[w4][cl], cn);
+                    cl = L[i];
+                    cn = 1;
+                }
+            }
+            atomicAdd(&h[w4][cl], cn);
+            u32_unaligned *wd = reinterpret_cast<u32_unaligned *>(labimg + (size_t)p * 3);
+            wd[0] = L[0] | (a[0] << 8) | (bb[0] << 16) | (L[1] << 24);
+            wd[1] = a[1] | (bb[1] << 8) | (L[2] << 16) | (a[2] << 24);
+            wd[2] = bb[2] | (L[3] << 8) | (a[3] << 16) | (bb[3] << 24);
+            continue;
+        }
         float v0[4], v1[4], v2[4];
         if (SRC == 2) {
             const Px4 q = n == 4 ? load_px4_any(img8 + (size_t)p * 3) : load_px4(img8 + (size_t)p * 3, n, false);

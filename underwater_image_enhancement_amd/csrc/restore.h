@@ -13,15 +13,18 @@ typedef double2 __attribute__((aligned(8))) double2_a8;
 
 // TAB: the float32 differences I - A of the 3 x 256 possible bytes come from a table in LDS (3 KB, filled by the
 // block in init(): the caller synchronises before the first use) instead of five operations per value.
-template <bool TAB>
+// TAB == 2: the table holds the differences already widened to float64 (6 KB; `lds_tab` then points at 768 doubles): the
+// quotient's numerator is one ds_read_b64, no conversion.
+template <int TAB>
 struct RestoreImgT {  // per image, in registers
     const uint8_t *img;
     const double *t;
     const float *tab;
     float a[3];
     bool att[3];
-    __device__ __forceinline__ void init(const RestoreSrc &S, int b, size_t npx, float *lds_tab = nullptr)
+    __device__ __forceinline__ void init(const RestoreSrc &S, int b, size_t npx, void *lds_tab_v = nullptr)
     {
+        float *lds_tab = static_cast<float *>(lds_tab_v);
         tab = lds_tab;
         const int k = S.kind ? S.kind[b] : 0;
         img = S.in + (size_t)b * npx * 3;
@@ -35,13 +38,21 @@ struct RestoreImgT {  // per image, in registers
             for (int i = threadIdx.x; i < 768; i += blockDim.x) {
                 const int c = i >> 8;
                 const float x = px_norm_fast((uint32_t)(i & 255));
-                lds_tab[i] = ((c == 0 ? att[0] : c == 1 ? att[1] : att[2]) ? x * 0.85f : x) - (c == 0 ? a[0] : c == 1 ? a[1] : a[2]);
+                const float d = ((c == 0 ? att[0] : c == 1 ? att[1] : att[2]) ? x * 0.85f : x) - (c == 0 ? a[0] : c == 1 ? a[1] : a[2]);
+                if (TAB == 2) static_cast<double *>(lds_tab_v)[i] = (double)d;
+                else lds_tab[i] = d;
             }
         }
     }
     // px_norm_fast(u) == u / 255.0f for every byte (tests/test_cabi.py), so this is px_val() without the division
+    __device__ __forceinline__ double diff64(uint32_t u, int c) const  // (double)diff(u, c)
+    {
+        if (TAB == 2) return reinterpret_cast<const double *>(tab)[c * 256 + u];
+        return (double)diff(u, c);
+    }
     __device__ __forceinline__ float diff(uint32_t u, int c) const
     {
+        if (TAB == 2) return (float)reinterpret_cast<const double *>(tab)[c * 256 + u];
         if (TAB) return tab[c * 256 + u];
         const float x = px_norm_fast(u);
         return (att[c] ? x * 0.85f : x) - a[c];
@@ -65,9 +76,38 @@ struct RestoreImgT {  // per image, in registers
     }
     __device__ __forceinline__ float one_fast(uint32_t u, int c, double tv, double y) const
     {
-        const double n = (double)diff(u, c), q0 = n * y;
+        const double n = diff64(u, c), q0 = n * y;
         const float v = (float)(fma(fma(-tv, q0, n), y, q0) + (double)a[c]);
         return fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+    // The same value before the clip (the caller tells 0 / 1 apart from the interior itself).
+    __device__ __forceinline__ float one_fast_raw(uint32_t u, int c, double tv, double y) const
+    {
+        const double n = diff64(u, c), q0 = n * y;
+        return (float)(fma(fma(-tv, q0, n), y, q0) + (double)a[c]);
+    }
+    // Four whole pixels p .. p+3 whose transmission is known to lie in [0.1, 1] (the guided filter's own clip, S6:180 /
+    // ES:232): no range test on the divisor, values NOT clipped.  w: the 12 frame bytes, tv: the four divisors.
+    __device__ __forceinline__ void four_raw(const uint32_t (&w)[3], const double (&tv)[4], float (&r)[3][4]) const
+    {
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const uint32_t ur[4] = {w0 & 255, w0 >> 24, (w1 >> 16) & 255, (w2 >> 8) & 255};
+        const uint32_t ug[4] = {(w0 >> 8) & 255, w1 & 255, w1 >> 24, (w2 >> 16) & 255};
+        const uint32_t ub[4] = {(w0 >> 16) & 255, (w1 >> 8) & 255, w2 & 255, w2 >> 24};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double y = recip(tv[i]);
+            r[0][i] = one_fast_raw(ur[i], 0, tv[i], y);
+            r[1][i] = one_fast_raw(ug[i], 1, tv[i], y);
+            r[2][i] = one_fast_raw(ub[i], 2, tv[i], y);
+        }
+    }
+    __device__ __forceinline__ void load_four(int p, uint32_t (&w)[3], double (&tv)[4]) const
+    {
+        const u32_any *q = reinterpret_cast<const u32_any *>(img + (size_t)p * 3);
+        w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
+        const double2_a8 ta = *reinterpret_cast<const double2_a8 *>(t + p), tb = *reinterpret_cast<const double2_a8 *>(t + p + 2);
+        tv[0] = ta.x; tv[1] = ta.y; tv[2] = tb.x; tv[3] = tb.y;
     }
     // pixels p .. p+3 (n of them exist); any alignment
     __device__ __forceinline__ void four(int p, int n, float (&r)[3][4]) const
@@ -163,6 +203,6 @@ struct RestoreImgT {  // per image, in registers
     }
 };
 
-using RestoreImg = RestoreImgT<false>;
+using RestoreImg = RestoreImgT<0>;
 
 }  // namespace uwie
