@@ -909,10 +909,10 @@ int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *s
 {
     UWIE_REQUIRE(split_row0 && split_rows, "guided_plan: NULL pointer");
     UWIE_CHECK_SHAPE(batch, H, W);
-    int iy0 = 0, band = 0, nb = 0;
-    const bool split = guided_split_plan(Shape{batch, H, W}, ksize, &iy0, &band, &nb);
+    int iy0 = 0, band = 0, nb = 0, rows = 0;
+    const bool split = guided_split_plan(Shape{batch, H, W}, ksize, &iy0, &band, &nb, &rows);
     *split_row0 = split ? iy0 : 0;
-    *split_rows = split ? std::min(band * nb, H - iy0) : 0;
+    *split_rows = split ? rows : 0;
     return UWIE_OK;
 }
 

@@ -184,7 +184,7 @@ bool guided_fast_handles(Shape s, int k);
 int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
                        hipStream_t st, bool ring_fx = false);
 // k_guided_pipe.hip: software-pipelined wavefront kernel for k in {10, 15, 20}; ring 0 = float64, 1 = fixed-point int32
-bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb);
+bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows = nullptr);
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
                        int *handled, hipStream_t st);
 

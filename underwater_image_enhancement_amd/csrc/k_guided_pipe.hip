@@ -658,7 +658,29 @@ struct RawRing<0> {
 
 struct SplitGeom {
     int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
+    int y_end;           // the last band runs to this row (shorter or longer than `band`; whole ring periods unless it is H)
     int xcd_fold;        // fold launch order so that an XCD's workgroups are neighbours (see k_guided_split)
+};
+
+// Per window width: row buffers in flight and whether the raw rows of the window ride in registers.
+//   K = 15: b ring 60 + raw ring 30 registers, three buffers (the round-2 kernel);  K = 10: 40 + 20, five buffers;
+//   K = 20: the b ring alone takes 80 registers, so the leaving raw row is re-read (t0 row 4 B + guide 1 B per slot), four buffers
+template <int K>
+struct SplitCfg {
+    static constexpr bool RAWREG = K <= 16;
+    static constexpr int NB = K % 3 == 0 ? 3 : K > 16 ? 2 : K % 5 == 0 ? 5 : 2;
+    // AR: rows of the a ring that live in registers next to b (ring slots 0 .. AR-1; compile-time slots, as for b).  The LDS
+    // of a strip decides how many wavefronts a CU holds: k = 20 with all 20 rows of a in LDS needs 23.1 KB (6 per CU), with
+    // three of them in registers (12 VGPRs) and the staging lines put FIRST -- so that the last lanes' look-ahead past the
+    // end of the last line lands in the ring instead of a pad -- 19.9 KB: eight per CU, two per SIMD, like k = 15.
+    static constexpr int AR = K > 16 ? 3 : 0;
+    static constexpr bool STAGE_FIRST = AR > 0;
+    // a ring + staged V1 (3072 B) + staged V2 (2048 B) [+ the look-ahead of the last lanes past the end of the last line]
+    static constexpr int pad_bytes = 16 * (PipeCfg<K>::M + 1) > 128 ? 16 * (PipeCfg<K>::M + 1) : 128;
+    static constexpr int s2_bytes = STAGE_FIRST ? 2048 : 2048 + pad_bytes;
+    static constexpr int ring_lds_bytes = (K - AR) * (PipeCfg<K>::NL + 1) * 16;
+    static_assert(!STAGE_FIRST || ring_lds_bytes >= pad_bytes, "the look-ahead must stay inside the allocation");
+    static constexpr int lds_bytes = ring_lds_bytes + PipeCfg<K>::s1_doubles * 8 + s2_bytes;
 };
 
 // Interior blocks only: every raw row/column the band touches exists (no reflection), W even, band % RC == 0.  Then a
@@ -671,11 +693,23 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
                                            const SplitGeom &g, const PipeConsts &cs, char *lds, int3 bid)
 {
     using C = PipeCfg<K>;
-    static_assert(K & 1, "odd window widths only (the entering row is the row just computed)");
-    constexpr int a = C::a, Lb = C::Lb, NV = C::NV, RC = C::RC, NL = C::NL, M = C::M, SW = C::SW;
-    static_assert(RC % 3 == 0, "the ring period must be a multiple of the three row buffers");
+    // Any window width (round 3: even ones too).  With the output row of an a/b row r taken as r - Lb (Lb = K - 1 - a rows
+    // below the anchor; = a for odd K) the a/b row that ENTERS the second box filter's window is always the row just
+    // computed and the one that leaves it is K rows older, so both rings have period K for odd and even K alike:
+    //     a/b row r   <- raw rows r - a .. r + Lb           (cv2.boxFilter's anchor k/2)
+    //     output row y <- a/b rows y - a .. y + Lb   =>   the window that ends at a/b row r belongs to output row r - Lb
+    constexpr int a = C::a, Lb = C::Lb, NV = C::NV, RC = K, NL = C::NL, M = C::M, SW = C::SW;
+    // row buffers in flight (loads are issued NB - 1 steps ahead); the ring period is a multiple of it
+    constexpr int NB = SplitCfg<K>::NB;
+    static_assert(RC % NB == 0, "the ring period must be a multiple of the row buffers");
+    // RAWREG: the last K raw transmission rows of a lane's slots ride in registers (no second read of t0); wide windows do
+    // not have the registers for it next to the b ring and re-read the leaving row
+    constexpr bool RAWREG = SplitCfg<K>::RAWREG;
     constexpr int NLp = NL + 1, EB = 16;
-    constexpr int ring_bytes = RC * NLp * EB;
+    constexpr int AR = SplitCfg<K>::AR;                              // a rows in registers (ring slots 0 .. AR-1)
+    constexpr int ring_bytes = SplitCfg<K>::ring_lds_bytes;          // a rows in LDS (ring slots AR .. RC-1)
+    constexpr uint32_t stage_base = SplitCfg<K>::STAGE_FIRST ? 0u : (uint32_t)ring_bytes;
+    constexpr uint32_t ring_base = SplitCfg<K>::STAGE_FIRST ? 3072u + 2048u : 0u;
     constexpr double K2 = (double)(K * K);
     const int lane = threadIdx.x;
     const int H = g.H, W = g.W;
@@ -710,7 +744,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         fix_odd[j] = sp & 1;
     }
 
-    const uint32_t a_ring = pipe_opaque((uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
+    const uint32_t a_ring = pipe_opaque(ring_base + (uint32_t)min(lane, NLp - 1) * (uint32_t)EB);
 
     // what the loads return, untouched (unpacked at the point of use: an early unpack would wait for the load at once)
 #ifndef SPLIT_RAW_G
@@ -720,9 +754,19 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         uint32_t te[2];         // entering raw row: float bits of the two slots
         uint32_t ge[2], go[2];  // its guide bytes / the guide bytes of the output row; !EDGE: [0] holds both bytes
         uint32_t gl[2];         // (SPLIT_RAW_G == 0) guide bytes of the leaving row
+        uint32_t tl[2];         // (!RAWREG) leaving raw row
     };
     auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
-    auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t ol_g, uint32_t oo_g, In &in) {
+    auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t ol_t, uint32_t ol_g, uint32_t oo_g, In &in) {
+        if constexpr (!RAWREG) {
+            if constexpr (!EDGE) {
+                const u32x2 tl = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], ol_t, 0);
+                in.tl[0] = tl.x; in.tl[1] = tl.y;
+            } else {
+                in.tl[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[0], ol_t, 0);
+                in.tl[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[1], ol_t, 0);
+            }
+        }
 #if !SPLIT_RAW_G
         if constexpr (!EDGE) in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
         else {
@@ -750,8 +794,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     double V1p[2] = {0.0, 0.0}, V1gp[2] = {0.0, 0.0};
     uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};
     double V2a[2] = {0.0, 0.0}, V2b[2] = {0.0, 0.0};
-    static_assert(K == RC, "odd window: the raw window of an a/b row is one ring period");
-    RawRing<RC> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
+    RawRing<RAWREG ? RC : 0> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
     auto prologue_row = [&](auto j_tag) {
         constexpr int J = decltype(j_tag)::value;
         const uint32_t row = (uint32_t)pipe_reflect(r_lo - a + J, H);  // rows above / below the image: BORDER_REFLECT_101
@@ -766,13 +809,15 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             V1p[c] += p;
             V1gp[c] += (double)gq[c] * p;
         }
-        raw.template set_at<J>(tb[0], tb[1], gq[0] | (gq[1] << 8));
+        if constexpr (RAWREG) raw.template set_at<J>(tb[0], tb[1], gq[0] | (gq[1] << 8));
     };
     [&]<int... J>(std::integer_sequence<int, J...>) { (prologue_row(IC<J>{}), ...); }(std::make_integer_sequence<int, RC>{});
     RegRing<RC> rb;
     rb.clear();
 #pragma unroll
-    for (int s = 0; s < RC; ++s) *reinterpret_cast<double2 *>(lds + a_ring + (uint32_t)(s * NLp * EB)) = make_double2(0.0, 0.0);
+    for (int s = 0; s < RC - AR; ++s) *reinterpret_cast<double2 *>(lds + a_ring + (uint32_t)(s * NLp * EB)) = make_double2(0.0, 0.0);
+    RegRing<AR> ra;  // the first AR rows of the a ring
+    ra.clear();
 
     // Staging, interleaved: the pair sums of TWO planes share a 16-byte entry, so a lane's look-ahead (entries l+1 .. l+M)
     // comes in as M ds_read_b128 that serve both planes (256 B/clk in the LDS, where the ds_read2_b64 pairs of separate
@@ -780,23 +825,31 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     // the end of a line lands in the next one and only feeds lanes whose sums are never stored.
     //   PP1[i] = {P_p, P_gp}   VV1[i] = {p0, gp0}    PI[i] = {P_g, P_gg}  VI[i] = {g0, gg0} (uint2)   -- staged V1
     //   PP2[i] = {P_a, P_b}    VV2[i] = {a0, b0}                                                       -- staged V2
-    const uint32_t a16 = pipe_opaque((uint32_t)ring_bytes + (uint32_t)lane * 16u);
-    const uint32_t a8 = pipe_opaque((uint32_t)ring_bytes + 2048u + (uint32_t)lane * 8u);
+    const uint32_t a16 = pipe_opaque(stage_base + (uint32_t)lane * 16u);
+    const uint32_t a8 = pipe_opaque(stage_base + 2048u + (uint32_t)lane * 8u);
     const double2 *pp1 = reinterpret_cast<const double2 *>(lds + a16), *vv1 = pp1 + SW;
     const uint2 *pi = reinterpret_cast<const uint2 *>(lds + a8), *vi = pi + SW;
     const double2 *pp2 = reinterpret_cast<const double2 *>(lds + a16 + 3072u), *vv2 = pp2 + SW;
-    static_assert(C::s1_doubles * 8 == 3072 && C::s2_doubles * 8 >= 2048 + 16 * (C::M + 1), "staging layout");
-    // window sums of a plane pair: o[0] = slots 2l .. 2l+K-1, o[1] = slots 2l+1 .. 2l+K (odd K)
+    static_assert(C::s1_doubles * 8 == 3072 && (SplitCfg<K>::STAGE_FIRST || SplitCfg<K>::s2_bytes >= 2048 + 16 * (C::M + 1)), "staging layout");
+    // window sums of a plane pair: o[0] = slots 2l .. 2l+K-1, o[1] = slots 2l+1 .. 2l+K
+    //   odd K  (M = (K-1)/2): o[0] = P[l] + P[l+1..l+M-1] + v0[l+M],   o[1] = v1[l] + P[l+1..l+M-1] + P[l+M]
+    //   even K (M = K/2):     o[0] = P[l] + P[l+1..l+M-1],             o[1] = v1[l] + P[l+1..l+M-1] + v0[l+M]
     auto window2 = [&](const double2 *pp, const double2 *vv, double2 P, double2 v1, double2 (&o)[2]) {
         double2 m0 = pp[1], m1 = pp[2];
 #pragma unroll
         for (int d = 3; d < M; d += 2) { const double2 t = pp[d]; m0.x += t.x; m0.y += t.y; }
 #pragma unroll
         for (int d = 4; d < M; d += 2) { const double2 t = pp[d]; m1.x += t.x; m1.y += t.y; }
-        const double2 f0 = vv[M], pm = pp[M];
+        const double2 f0 = vv[M];
         const double midx = m0.x + m1.x, midy = m0.y + m1.y;
-        o[0] = make_double2((P.x + midx) + f0.x, (P.y + midy) + f0.y);
-        o[1] = make_double2((v1.x + midx) + pm.x, (v1.y + midy) + pm.y);
+        if constexpr (K & 1) {
+            const double2 pm = pp[M];
+            o[0] = make_double2((P.x + midx) + f0.x, (P.y + midy) + f0.y);
+            o[1] = make_double2((v1.x + midx) + pm.x, (v1.y + midy) + pm.y);
+        } else {
+            o[0] = make_double2(P.x + midx, P.y + midy);
+            o[1] = make_double2((v1.x + midx) + f0.x, (v1.y + midy) + f0.y);
+        }
     };
     auto stage_v1 = [&]() {
         const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
@@ -809,7 +862,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     auto step = [&](auto warm_tag, auto slot_tag, const In &in, uint32_t orow, bool row_ok) {
         constexpr bool WARM = decltype(warm_tag)::value;
         constexpr int S = decltype(slot_tag)::value;
-        char *ring_p = lds + a_ring + (uint32_t)(S * NLp * EB);
+        char *ring_p = lds + a_ring + (uint32_t)((S >= AR ? S - AR : 0) * NLp * EB);
 
         // ================= read phase
         double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
@@ -825,11 +878,18 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 #pragma unroll
             for (int d = 4; d < M; d += 2) { m1.x += ps[d].x; m1.y += ps[d].y; }
             const uint32_t midg = m0.x + m1.x, midgg = m0.y + m1.y;
-            const uint2 f0 = vi[M], pm = ps[M];
-            oG[0] = Sg[0] + Sg[1] + midg + f0.x;   oGG[0] = Sgg[0] + Sgg[1] + midgg + f0.y;
-            oG[1] = Sg[1] + midg + pm.x;           oGG[1] = Sgg[1] + midgg + pm.y;
+            const uint2 f0 = vi[M];
+            if constexpr (K & 1) {
+                const uint2 pm = ps[M];
+                oG[0] = Sg[0] + Sg[1] + midg + f0.x;   oGG[0] = Sgg[0] + Sgg[1] + midgg + f0.y;
+                oG[1] = Sg[1] + midg + pm.x;           oGG[1] = Sgg[1] + midgg + pm.y;
+            } else {
+                oG[0] = Sg[0] + Sg[1] + midg;          oGG[0] = Sgg[0] + Sgg[1] + midgg;
+                oG[1] = Sg[1] + midg + f0.x;           oGG[1] = Sgg[1] + midgg + f0.y;
+            }
         }
-        const double2 la = *reinterpret_cast<const double2 *>(ring_p);  // a of the leaving row (same slot)
+        double2 la = make_double2(0.0, 0.0);  // a of the leaving row (same slot)
+        if constexpr (S >= AR) la = *reinterpret_cast<const double2 *>(ring_p);
 
         // ================= compute
         if constexpr (!WARM) {  // C: q = mean_a * I + mean_b, clip (six_stadigy.py:45,180)
@@ -875,11 +935,16 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         }
         double lb0 = bv[0], lb1 = bv[1];
         rb.template swap_at<S>(lb0, lb1);  // registers: new b in, b of the leaving row out
+        if constexpr (S < AR) {
+            la = make_double2(av[0], av[1]);
+            ra.template swap_at<S>(la.x, la.y);
+        }
         V2a[0] += av[0] - la.x; V2a[1] += av[1] - la.y;
         V2b[0] += bv[0] - lb0;  V2b[1] += bv[1] - lb1;
         // A: V1 += raw(entering) - raw(leaving); the entering row takes the leaving row's place in the register ring
         uint32_t lt[2] = {in.te[0], in.te[1]}, lg = EDGE ? (in.ge[0] | (in.ge[1] << 8)) : in.ge[0];
-        raw.template swap_at<S>(lt[0], lt[1], lg);
+        if constexpr (RAWREG) raw.template swap_at<S>(lt[0], lt[1], lg);
+        else { lt[0] = in.tl[0]; lt[1] = in.tl[1]; }
 #if !SPLIT_RAW_G
         lg = EDGE ? (in.gl[0] | (in.gl[1] << 8)) : in.gl[0];
 #endif
@@ -898,7 +963,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         stage_v1();
         const_cast<double2 *>(pp2)[0] = make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]);
         const_cast<double2 *>(vv2)[0] = make_double2(V2a[0], V2b[0]);
-        *reinterpret_cast<double2 *>(ring_p) = make_double2(av[0], av[1]);
+        if constexpr (S >= AR) *reinterpret_cast<double2 *>(ring_p) = make_double2(av[0], av[1]);
         pipe_sync();
     };
 
@@ -910,20 +975,19 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     // and bottom borders need -- a/b "rows" above row 0 computed from reflected raw rows ARE the a/b rows cv2.boxFilter's
     // BORDER_REFLECT_101 mirrors in (the window of virtual row -j reflects onto the window of row j), and likewise below.
     const int i0 = r_lo + 1;
-    int re = i0 + Lb;       // entering raw row of the next load (the leaving guide row is re - RC)
-    int gr = i0 - a - 2;    // guide row that rides with the next load: the load issued at step i (the third load) serves
-                            // step i+2, whose C phase stores row i-a (unused before the first normal step)
+    int re = i0 + Lb;       // entering raw row of the next load (the leaving row is re - RC)
+    int gr = i0 - Lb - 2;   // guide row that rides with the next load: the load issued at step i (NB - 1 steps ahead) serves
+                            // step i + NB - 1, whose C phase stores row i + NB - 3 - Lb (unused before the first normal step)
     int yo = y_lo;          // row the next normal step stores
     auto issue = [&](In &fill) {
         const uint32_t er = (uint32_t)pipe_reflect(re, H), lr = (uint32_t)pipe_reflect(re - RC, H);
         const uint32_t og = (uint32_t)min(max(gr, 0), H - 1);
-        load_rows(er * pitch_t, er * pitch_g, lr * pitch_g, og * pitch_g, fill);
+        load_rows(er * pitch_t, er * pitch_g, lr * pitch_t, lr * pitch_g, og * pitch_g, fill);
         ++re;
         ++gr;
     };
-    In b0, b1, b2;
-    issue(b0);
-    issue(b1);
+    In buf[NB];  // (indexed by compile-time constants only)
+    [&]<int... Q>(std::integer_sequence<int, Q...>) { (issue(buf[Q]), ...); }(std::make_integer_sequence<int, NB - 1>{});
     auto one = [&](auto warm_tag, auto slot_tag, In &fill, const In &use) {
         issue(fill);
         step(warm_tag, slot_tag, use, (uint32_t)yo * pitch_o, yo < H);
@@ -931,18 +995,17 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         __builtin_amdgcn_sched_barrier(0);  // one step's LDS reads are not stretched over its neighbours (VGPR budget)
     };
     auto period = [&](auto warm_tag) {
-        auto triple = [&](auto base_tag) {
-            constexpr int S0 = decltype(base_tag)::value;
-            one(warm_tag, IC<S0>{}, b2, b0);
-            one(warm_tag, IC<S0 + 1>{}, b0, b1);
-            one(warm_tag, IC<S0 + 2>{}, b1, b2);
+        // step with ring slot S uses buffer S % NB and refills the buffer the previous step used
+        auto at = [&](auto slot_tag) {
+            constexpr int S = decltype(slot_tag)::value;
+            one(warm_tag, slot_tag, buf[(S + NB - 1) % NB], buf[S % NB]);
         };
-        [&]<int... Q>(std::integer_sequence<int, Q...>) { (triple(IC<3 * Q>{}), ...); }(std::make_integer_sequence<int, RC / 3>{});
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (at(IC<Q>{}), ...); }(std::make_integer_sequence<int, RC>{});
     };
     // warm period: steps r_lo+1 .. r_lo+RC (slots 0 .. RC-1)
     period(std::true_type{});
     // normal periods: the band's rows (the last band stops at the image's last row)
-    const int nper = (min(g.band, H - y_lo) + RC - 1) / RC;
+    const int nper = (((int)bid.y == (int)gridDim.y - 1 ? g.y_end - y_lo : g.band) + RC - 1) / RC;
     for (int p = 0; p < nper; ++p) period(std::false_type{});
 }
 
@@ -975,13 +1038,13 @@ k_guided_split(const uint8_t *__restrict__ gray, const float *__restrict__ t0, T
 
 template <int K, typename TOut>
 int launch_split(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, int y0, int band, int nbands,
-                 hipStream_t st)
+                 int y_end, hipStream_t st)
 {
     using C = PipeCfg<K>;
-    constexpr int lds = C::RC * (C::NL + 1) * 16 + (C::s1_doubles + C::s2_doubles) * 8;
+    constexpr int lds = SplitCfg<K>::lds_bytes;
     const char *e_fold = getenv("UWIE_GF_XCD");  // (experiment knob, read per call)
     const bool fold = !(e_fold && e_fold[0] == '0');
-    SplitGeom g{s.H, s.W, y0, band, fold ? 1 : 0};
+    SplitGeom g{s.H, s.W, y0, band, y_end, fold ? 1 : 0};
     const int nstrips = cdiv(s.W, C::NV);
     {
         UWIE_PROF("k_guided_split", st);
@@ -1029,30 +1092,44 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
 
 }  // namespace
 
-// Rows [*iy0, min(H, *iy0 + *nb * *band)) go to k_guided_split (float64 ring, k = 15, an even W, a job large enough to fill
-// the chip with long bands): all of them since the kernel reflects row indices itself; false = the general kernel alone.
-bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb)
+// Rows [*iy0, min(H, *iy0 + *nb * *band)) go to k_guided_split (float64 ring; k = 10, 15 or 20, an even W, a job large enough
+// to fill the chip with long bands); false = the general kernel alone.
+//   odd k:  every row -- the kernel reflects row indices itself, which is exact for a symmetric window;
+//   even k: the window [y - k/2, y + k/2 - 1] is not symmetric, so a virtual a/b row above row 0 built from reflected raw rows
+//           is NOT the a/b row cv2.boxFilter mirrors in: the split kernel takes the whole bands between row k and row
+//           H - (k - 2) (no reflection anywhere in them), the general kernel the rows above and below (launch_pipe, border).
+bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
 {
+    if (rows) *rows = 0;
     const char *env_split = getenv("UWIE_GF_SPLIT");
-    if (k != 15 || (s.W & 1) || (env_split && atoi(env_split) == 0)) return false;
+    if ((k != 10 && k != 15 && k != 20) || (s.W & 1) || (env_split && atoi(env_split) == 0)) return false;
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || s.npx() >= ((size_t)1 << 27)) return false;
-    using C = PipeCfg<15>;
-    *iy0 = 0;  // every row: the kernel reflects row indices at the top and bottom borders
-    const int periods = cdiv(s.H, C::RC);
+    const int RC = k, a = k / 2, Lb = k - 1 - a, NV = kPipeSlots - 2 * (k - 1);
+    const bool odd = k & 1;
+    *iy0 = odd ? 0 : 2 * a;
+    const int periods = odd ? cdiv(s.H, RC) : (s.H - 2 * a - 2 * Lb) / RC;
     if (periods < 4) return false;
-    const long strips = (long)cdiv(s.W, C::NV) * s.B;
+    const long strips = (long)cdiv(s.W, NV) * s.B;
     const char *env_b = getenv("UWIE_GF_BANDS");
     int n;
     if (env_b) n = atoi(env_b);
     else {
         // ~8 wavefronts per resident slot (256 CUs x 8) even out the tail; a band costs one extra ring period
         n = (int)cdiv((size_t)(8L * 2048), (size_t)strips);
-        n = std::min(n, std::max(1, periods / 12));  // ... but at least 12 periods (180 rows) long
+        n = std::min(n, std::max(1, periods * RC / 180));  // ... but at least ~180 rows long
     }
     n = std::max(1, std::min(n, periods));
-    const int per_band = cdiv(periods, n);
-    *band = C::RC * per_band;
-    *nb = cdiv(periods, per_band);  // the last band may be shorter (it stops at the image's last row)
+    if (odd) {
+        const int per_band = cdiv(periods, n);
+        *band = RC * per_band;
+        *nb = cdiv(periods, per_band);  // the last band may be shorter (it stops at the image's last row)
+        if (rows) *rows = s.H;
+    } else {
+        const int per_band = periods / n;  // whole periods only: the last band takes the periods that are left over
+        *band = RC * per_band;
+        *nb = periods / per_band;
+        if (rows) *rows = periods * RC;
+    }
     // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
     return env_b || strips * n >= 1024;
 }
@@ -1091,11 +1168,23 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
         cs.kb = scale;
         cs.b0 = 0.0;
     }
-    // float64, k = 15: the split-ring kernel.  UWIE_GF_SPLIT=0 (read per call) keeps the general kernel.
+    // float64: the split-ring kernel.  UWIE_GF_SPLIT=0 (read per call) keeps the general kernel.
     if (ring == 0) {
-        int iy0, band, nb;
-        if (guided_split_plan(s, k, &iy0, &band, &nb)) {
-            UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, st)));
+        int iy0, band, nb, rows;
+        if (guided_split_plan(s, k, &iy0, &band, &nb, &rows)) {
+            if (k == 15) {
+                UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, s.H, st)));
+            } else {
+                // even window: rows [0, iy0) and [iy0 + rows, H) around the split kernel's whole periods
+                const int border[6] = {iy0, iy0 + rows, band, 0, 0, 0};
+                if (k == 20) {
+                    UWIE_TRY_RC((launch_split<20, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, iy0 + rows, st)));
+                    UWIE_TRY_RC((launch_pipe<20, false, double>(d_gray, d_t0, s, cs, d_t, st, border)));
+                } else {
+                    UWIE_TRY_RC((launch_split<10, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, iy0 + rows, st)));
+                    UWIE_TRY_RC((launch_pipe<10, false, double>(d_gray, d_t0, s, cs, d_t, st, border)));
+                }
+            }
             *handled = 1;
             return UWIE_OK;
         }
