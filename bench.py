@@ -145,12 +145,12 @@ def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
     return table[key]["hbm_bytes_per_px_per_step"] * B * H * W / max(launches_per_step, 1)
 
 
-def timed_enhance(dev, _lib, torch, frames, strategy, steps):
+def timed_enhance(dev, _lib, torch, frames, strategy, steps, **overrides):
     """ms per call of uwie_enhance_u8 on `frames` (one warm-up, then `steps` calls between two synchronisations)."""
     import ctypes
 
     B, H, W = frames.shape[:3]
-    p = dev.params(_lib.SURFACE_SIX, strategy)
+    p = dev.params(_lib.SURFACE_SIX, strategy, **overrides)
     ws = dev.workspace_for(B, H, W, p)
     out = dev.empty((B, H, W, 3), torch.uint8)
 
@@ -188,6 +188,19 @@ def extras(dev, args, torch, _lib):
     finally:
         del os.environ["UWIE_STREAMS"]
     res["two_streams_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
+    # opt-in: reduced-precision intermediates (BASELINE.json configs[4]; uwie_params.inter_dtype = UWIE_INTER_F32T: float32
+    # transmission plane and float32 restore, its own stated tolerance -- tests/test_gpu_fuzz.py); the two sweeps it
+    # shortens are reported for both modes (HIP events around the kernels of one recorded step each)
+    if args.strategy in (1, 2, 3):
+        ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 3, inter_dtype=_lib.INTER_F32T)
+        res["f32t_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
+        for tag, mode in (("f64", _lib.INTER_F64), ("f32t", _lib.INTER_F32T)):
+            dev.profile(True)
+            timed_enhance(dev, _lib, torch, fr, args.strategy, 1, inter_dtype=mode)
+            rows = dev.profile_rows()
+            dev.profile(False)
+            res[f"{tag}_restore_hist_plus_stretch_lab_ms"] = round(
+                sum(v[0] / max(v[1], 1) for n, v in rows.items() if n.startswith(("k_restore_hist_collect", "k_stretch_lab_lut"))), 3)
     del fr
     # N1: the batch driver's fan-out, all six strategies per frame with shared cast detection / quadtree
     fan = synth_frames("underwater", min(B, 16), H, W, dev.torch_device, seed=1000 * 2)

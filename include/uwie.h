@@ -82,11 +82,20 @@ typedef struct uwie_params {
                               once to 2^-31 / 2^-30, every sum stays exact; |t - t_exact| <= 5e-10; u8 output: about
                               one byte in 1e6-1e7 differs, by 1 LSB before CLAHE and up to CLAHE's local slope
                               after it -- tests/test_gpu_fuzz.py).  SIX surface only (needs the pre-clipped transmission, S6:174); other
-                              cases silently keep float64.                                                */
+                              cases silently keep float64.
+                              UWIE_INTER_F32T (round 3; BASELINE.json configs[4] "fp16 intermediates ... stated tolerance"):
+                              the refined transmission (S6:180) is stored as float32 and restore_image (S6:183-188) runs in
+                              float32 with a reciprocal instead of the float64 division: half the bytes of the t plane, a
+                              quarter of the restore arithmetic.  NOT the <= 1 LSB mode -- its own contract against the float64
+                              path: >= 99.98 % of the u8 bytes identical, <= 5e-5 of them off by more than 1 LSB, none by more
+                              than 10, PSNR >= 80 dB (tests/test_gpu_fuzz.py::test_f32t_transmission_stated_tolerance).  SIX
+                              surface, strategies 1-3, windows 10 / 15 / 20 on frames the wavefront kernels take (even W,
+                              H >= 4k, W >= 2k); everything else silently keeps float64.                         */
 } uwie_params;
 
 #define UWIE_INTER_F64 0
 #define UWIE_INTER_FX32 1
+#define UWIE_INTER_F32T 2
 
 const char *uwie_last_error(void);
 const char *uwie_version(void);
@@ -234,8 +243,11 @@ int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, 
                        double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Which rows of a frame the default float64 guided filter (gf_exact = 0, inter_dtype = F64) hands to its main kernel
- * (k_guided_split: rows [*split_row0, *split_row0 + *split_rows)); the rows around them go to the general kernel in a
- * second launch.  0 rows = the general kernel alone.  For benchmarks that price each kernel by the pixels it covers. */
+ * (k_guided_split: rows [*split_row0, *split_row0 + *split_rows)).  ksize 15: every row of the frame, one launch (the
+ * kernel reflects row indices at the top and bottom borders itself).  ksize 10 / 20 (non-symmetric window): the whole
+ * ring periods between row ksize and row H - (ksize - 2); the rows above and below go to the general kernel
+ * (k_guided_pipe) in a second launch.  0 rows = the general kernel alone (small jobs, odd widths, other windows).
+ * For benchmarks that price each kernel by the pixels it covers. */
 int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *split_rows);
 
 /* restore_image (S6:183-188): float32 [batch][H][W][3]. */

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libuwie.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 SURFACE_SIX, SURFACE_DICT = 0, 1
+INTER_F64, INTER_FX32, INTER_F32T = 0, 1, 2  # uwie_params.inter_dtype
 DICT_STRATEGIES = {
     "strong_dehazing": 0,
     "medium_dehazing": 1,

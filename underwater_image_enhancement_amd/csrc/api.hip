@@ -123,9 +123,19 @@ uwie_params merged_params(const uwie_params *ps, int n, Shape s)
     return m;
 }
 
-int stage_guided(uwie_ctx *ctx, const Pipe &P, Shape s, const uwie_params *p, hipStream_t st)
+// *t_is_f32 (optional): set when the transmission was written as float32 (UWIE_INTER_F32T and a window / frame the
+// wavefront kernels take); everything downstream reads it through RestoreSrc::t32
+int stage_guided(uwie_ctx *ctx, const Pipe &P, Shape s, const uwie_params *p, hipStream_t st, int *t_is_f32 = nullptr)
 {
     int handled = 0;
+    if (t_is_f32) *t_is_f32 = 0;
+    if (t_is_f32 && p->inter_dtype == UWIE_INTER_F32T && !p->gf_exact && p->surface == UWIE_SURFACE_SIX) {
+        UWIE_TRY(launch_guided_pipe(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, 0, P.t, &handled, st, true));
+        if (handled) {
+            *t_is_f32 = 1;
+            return UWIE_OK;
+        }
+    }
     // fixed-point a/b ring: only with the pre-clipped transmission of the six_stadigy surface (0.1 <= t0 <= 1 bounds a, b).
     // UWIE_GF_RING=1 (read per call, experiments) forces it like inter_dtype = UWIE_INTER_FX32.
     const char *env_ring = getenv("UWIE_GF_RING");
@@ -171,18 +181,19 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     const float eps = 1e-6f;  // six_stadigy.py:198,218
     const int k = p->strategy;
     UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, (float)p->omega, 1e-6f, 1, P.t0, st));
-    UWIE_TRY(stage_guided(ctx, P, s, p, st));
+    int t_is_f32 = 0;
+    UWIE_TRY(stage_guided(ctx, P, s, p, st, &t_is_f32));
     // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
     SelectPlan plan;
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
     // the restored image is clipped to [0, 1]: linear first digit, one collecting sweep (k_select.hip, select_lin_*);
     // UWIE_SELECT_GENERIC=1 keeps the three-digit key sweeps
     const char *env_generic = getenv("UWIE_SELECT_GENERIC");  // read per call
-    const RestoreSrc src{d_in, kind, P.A, P.t};
+    const RestoreSrc src{d_in, kind, P.A, P.t, t_is_f32};
     bool recompute = false;
     if (env_generic && atoi(env_generic) == 1) {
         UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
-        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st));
+        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st, false, nullptr, nullptr, t_is_f32));
         UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
     } else {
         // Strategies 1 and 2 never store the restored image: the histogram sweep (which also files the elements of the
@@ -200,7 +211,7 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         const bool predict = k != 3 || (env_p3 && atoi(env_p3) == 1);
         UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, predict ? &src : nullptr));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
-                                            &plan));
+                                            &plan, t_is_f32));
         UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
     }
     if (k == 3) {
@@ -276,7 +287,8 @@ int check_params(const uwie_params *p)
                  "L_low / L_high must be percentiles in [0, 100]");
     if (p->surface == UWIE_SURFACE_SIX && (p->strategy >= 3 && p->strategy <= 5))
         UWIE_REQUIRE(p->wb_percentile >= 0.0 && p->wb_percentile <= 100.0, "wb_percentile must be in [0, 100]");
-    UWIE_REQUIRE(p->inter_dtype == UWIE_INTER_F64 || p->inter_dtype == UWIE_INTER_FX32, "unknown inter_dtype");
+    UWIE_REQUIRE(p->inter_dtype == UWIE_INTER_F64 || p->inter_dtype == UWIE_INTER_FX32 || p->inter_dtype == UWIE_INTER_F32T,
+                 "unknown inter_dtype");
     return UWIE_OK;
 }
 

@@ -185,8 +185,10 @@ int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
                        hipStream_t st, bool ring_fx = false);
 // k_guided_pipe.hip: software-pipelined wavefront kernel for k in {10, 15, 20}; ring 0 = float64, 1 = fixed-point int32
 bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows = nullptr);
+// out_f32: d_t is written as float32 (UWIE_INTER_F32T); only the pipe / split kernels do that, so *handled = 0 then means
+// "not taken, nothing written"
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
-                       int *handled, hipStream_t st);
+                       int *handled, hipStream_t st, bool out_f32 = false);
 
 // k_select.hip
 constexpr int kMaxPct = 4;  // percentiles per call
@@ -280,12 +282,14 @@ struct RestoreSrc {
     const uint8_t *in;    // [B][H][W][3]
     const int32_t *kind;  // [B] cast kinds or nullptr
     const float *A;       // [B][3]
-    const double *t;      // [B][H][W]
+    const double *t;      // [B][H][W]; float32 data when t32 is set (uwie_params.inter_dtype = UWIE_INTER_F32T)
+    int t32 = 0;
 };
 // plan != nullptr: the linear-digit histogram goes to plan->ghist and the elements of the predicted windows to the lists
+// t32: d_t holds float32 data (RestoreSrc::t32)
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                                float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false,
-                               const uint32_t *d_only = nullptr, const SelectPlan *plan = nullptr);
+                               const uint32_t *d_only = nullptr, const SelectPlan *plan = nullptr, int t32 = 0);
 size_t tail_ws_bytes(Shape s, int tx, int ty);
 // d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,

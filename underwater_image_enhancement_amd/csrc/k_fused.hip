@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         for (int i = tid; i < 3 * NB; i += 256) (&h[0][0])[i] = 0;
         if (tid < NS) scount[tid] = 0;
     }
-    RestoreImgT<FAST ? 2 : 0> R;
+    // the whole sweep for one flavour of the restore (float64 quotient, or UWIE_INTER_F32T's float32 one)
+    auto sweep = [&](auto &R) {
     R.init(S, b, (size_t)npx, dtab);
     __syncthreads();
     V *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
@@ -290,6 +291,16 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         const uint32_t c = (&h[0][0])[i] & (COLLECT ? kCntMask : 0xffffffffu);
         if (c) atomicAdd(&ghist[(size_t)(b * 3 + i / NB) * kSelGroupStride + (i % NB)], c);
     }
+    };  // sweep
+    if constexpr (FAST) {
+        if (S.t32) {
+            RestoreImgT<2, true> R;
+            sweep(R);
+            return;
+        }
+    }
+    RestoreImgT<FAST ? 2 : 0> R;
+    sweep(R);
 }
 
 struct Stretch {  // per image: lo and denominator per channel, for one or two chained stretches
@@ -387,7 +398,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
     const uint8_t *img8 = src.in + (size_t)b * npx * 3;
     __shared__ double dtab[SRC == 1 ? 768 : 1];
-    RestoreImgT<2> R;
+    // the tile's pixels for one flavour of the restore (float64 quotient, or UWIE_INTER_F32T's float32 one)
+    auto pixels = [&](auto &R) {
     if (SRC == 1) {
         R.init(src, b, (size_t)npx, dtab);
         __syncthreads();
@@ -573,6 +585,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
             to_lab(e0, e1, e2, L, a, bb);
             atomicAdd(&h[w][L], 1u);
         }
+    }
+    };  // pixels
+    if (SRC == 1 && src.t32) {
+        RestoreImgT<2, true> R;
+        pixels(R);
+    } else {
+        RestoreImgT<2> R;
+        pixels(R);
     }
     __syncthreads();
     uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
@@ -1073,7 +1093,7 @@ float gamma_exponent(int mode, double g) { return mode == 1 ? (float)g : mode ==
 
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                                float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear, const uint32_t *d_only,
-                               const SelectPlan *plan)
+                               const SelectPlan *plan, int t32)
 {
     // 24.6 KB of LDS per block: six blocks per CU, 1536 resident on the chip.  Enough blocks for several full rounds
     // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
@@ -1083,7 +1103,7 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
-    const RestoreSrc S{d_in, d_kind, d_A, d_t};
+    const RestoreSrc S{d_in, d_kind, d_A, d_t, t32};
     const dim3 grid(nblk, s.B);
     const auto k_restore_hist_collect = k_restore_planar_hist<true, true, 2>;  // (names as the profiler reports them)
     const auto k_restore_hist_collect4 = k_restore_planar_hist<true, true, 4>;

@@ -1137,9 +1137,10 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
 // ring: 0 = float64 (split ring where guided_split_plan takes the job), 1 = fixed-point int32 (requires 0.1 <= t0 <= 1:
 // the caller's pre-clip, six_stadigy.py:174)
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
-                       int *handled, hipStream_t st)
+                       int *handled, hipStream_t st, bool out_f32)
 {
     *handled = 0;
+    if (out_f32 && (ring != 0 || (s.W & 1))) return UWIE_OK;  // float32 output: float64 ring, paired stores
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || !(eps > 0.0)) return UWIE_OK;
     if (k != 10 && k != 15 && k != 20) return UWIE_OK;
     const double K2 = (double)k * k, scale = 1.0 / K2;
@@ -1171,6 +1172,31 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
     // float64: the split-ring kernel.  UWIE_GF_SPLIT=0 (read per call) keeps the general kernel.
     if (ring == 0) {
         int iy0, band, nb, rows;
+        if (out_f32) {
+            // UWIE_INTER_F32T: the same kernels with a float32 store (q is rounded once, after the clip)
+            float *d_tf = reinterpret_cast<float *>(d_t);
+            const bool split = guided_split_plan(s, k, &iy0, &band, &nb, &rows);
+            const int border[6] = {iy0, iy0 + rows, band, 0, 0, 0};
+            int rc = UWIE_OK;
+            switch (k) {
+            case 15:
+                rc = split ? launch_split<15, float>(d_gray, d_t0, s, cs, d_tf, iy0, band, nb, s.H, st)
+                           : launch_pipe<15, false, float>(d_gray, d_t0, s, cs, d_tf, st);
+                break;
+            case 20:
+                rc = split ? launch_split<20, float>(d_gray, d_t0, s, cs, d_tf, iy0, band, nb, iy0 + rows, st)
+                           : launch_pipe<20, false, float>(d_gray, d_t0, s, cs, d_tf, st);
+                if (rc == UWIE_OK && split) rc = launch_pipe<20, false, float>(d_gray, d_t0, s, cs, d_tf, st, border);
+                break;
+            default:
+                rc = split ? launch_split<10, float>(d_gray, d_t0, s, cs, d_tf, iy0, band, nb, iy0 + rows, st)
+                           : launch_pipe<10, false, float>(d_gray, d_t0, s, cs, d_tf, st);
+                if (rc == UWIE_OK && split) rc = launch_pipe<10, false, float>(d_gray, d_t0, s, cs, d_tf, st, border);
+                break;
+            }
+            if (rc == UWIE_OK) *handled = 1;
+            return rc;
+        }
         if (guided_split_plan(s, k, &iy0, &band, &nb, &rows)) {
             if (k == 15) {
                 UWIE_TRY_RC((launch_split<15, double>(d_gray, d_t0, s, cs, d_t, iy0, band, nb, s.H, st)));

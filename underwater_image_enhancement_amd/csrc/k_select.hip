@@ -442,10 +442,13 @@ __global__ void __launch_bounds__(256) k_lin_sample(RestoreSrc S, int npx, int s
     for (int i = tid; i < 3 * kLinBins; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
     RestoreImg R;
-    R.init(S, b, (size_t)npx);
+    RestoreImg32 R32;  // UWIE_INTER_F32T (float32 planes only)
+    if (S.t32) R32.init(S, b, (size_t)npx);
+    else R.init(S, b, (size_t)npx);
     for (int i = blockIdx.x * 256 + tid; i < ngs; i += gridDim.x * 256) {
         V r[3][4];
         if constexpr (sizeof(V) == 8) R.four64((i * stride + stride / 2) * 4, 4, r);  // (ES surface: the float64 image)
+        else if (S.t32) R32.four((i * stride + stride / 2) * 4, 4, r);
         else R.four((i * stride + stride / 2) * 4, 4, r);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -685,7 +688,9 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
     if (tid < 3 * NG) scount[tid] = 0;
     __syncthreads();
     RestoreImg R;
-    R.init(S, b, (size_t)n);
+    RestoreImg32 R32;  // UWIE_INTER_F32T (float32 planes only)
+    if (S.t32) R32.init(S, b, (size_t)n);
+    else R.init(S, b, (size_t)n);
     const int per = (((n + 3) / 4 + gridDim.x - 1) / gridDim.x) * 4;
     const int lo = min(n, blockIdx.x * per), hi = min(n, lo + per);
     auto take = [&](int c, V x, bool live) {
@@ -731,6 +736,7 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
             if (m > 0) {
                 V r[3][4];
                 if constexpr (sizeof(V) == 8) R.four64(p, m, r);
+                else if (S.t32) R32.four(p, m, r);
                 else R.four(p, m, r);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -957,7 +963,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
     if (src) {
-        const int rc = launch_restore_planar_hist(src->in, src->kind, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags);
+        const int rc = launch_restore_planar_hist(src->in, src->kind, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags, nullptr, src->t32);
         if (rc != UWIE_OK) return rc;
     }
     UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_restore(RestoreSrc S, int npx, float *_
 {
     const int b = blockIdx.y;
     RestoreImg R;
-    R.init(S, b, (size_t)npx);
+    R.init(S, b, (size_t)npx);  // (the stage entry point takes the float64 transmission only)
     for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) {
         float *o = out + ((size_t)b * npx + p) * 3;
         R.pixel(p, o[0], o[1], o[2]);
