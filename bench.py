@@ -35,7 +35,7 @@ KERNEL_BYTES_PER_PX = {
     "k_chunk_hist": 3, "k_chunk_ulps": 0, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
     "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_gradnms<true>": 1 * Q, "k_canny_gradnms<false>": (1 + 1) * Q,
     "k_canny_union": 1 * Q, "k_canny_mark": 1 * Q, "k_canny_emit": 1 * Q,
-    "k_trans_init": 3 + 4, "k_guided_fast<TH>": 1 + 4 + 8, "k_guided_wave": 1 + 4 + 8,
+    "k_trans_init": 3 + 4, "k_guided_fast<TH>": 1 + 4 + 8,
     # the default guided filter is two launches that split the rows of a frame (uwie_guided_plan): main() scales these by
     # the fraction of the rows each covers
     "k_guided_split": 1 + 4 + 8, "k_guided_pipe": 1 + 4 + 8,
@@ -180,13 +180,10 @@ def extras(dev, args, torch, _lib):
         ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 2)
         res[f"{dist}_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
         del fr
-    # opt-in: sub-batches on two streams (UWIE_STREAMS=2), whole-job rate on the headline workload
+    # opt-in: sub-batches on two streams (tuning streams = 2), whole-job rate on the headline workload
     fr = synth_frames(args.dist, B, H, W, dev.torch_device, seed=1000 * 2)
-    os.environ["UWIE_STREAMS"] = "2"
-    try:
+    with dev.tuning(streams=2):
         ms = timed_enhance(dev, _lib, torch, fr, args.strategy, 3)
-    finally:
-        del os.environ["UWIE_STREAMS"]
     res["two_streams_megapixels_per_sec"] = round(B * H * W / 1e3 / ms, 1)
     # opt-in: reduced-precision intermediates (BASELINE.json configs[4]; uwie_params.inter_dtype = UWIE_INTER_F32T: float32
     # transmission plane and float32 restore, its own stated tolerance -- tests/test_gpu_fuzz.py); the two sweeps it

@@ -16,11 +16,9 @@ for k in (1, 2, 3):
     for name, u8 in frames.items():
         want = orc.enhance_u8(u8, k)
         row = []
-        for env in ({}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_SELECT_GENERIC": "1"}, {"UWIE_LIN_NO_PREDICT": "1"}):
-            os.environ.update(env)
-            got = uw.enhance(u8, strategy=k)
-            for e in env:
-                del os.environ[e]
+        for env in ({}, {"restore_store": 1}, {"select_generic": 1}, {"lin_no_predict": 1}):
+            with uw.get_device().tuning(**env):
+                got = uw.enhance(u8, strategy=k)
             d = np.abs(got.astype(int) - want.astype(int))
             row.append(f"{list(env) or 'default'}: max {d.max()} n {np.count_nonzero(d)}")
         print(k, name, u8.shape, " | ".join(row))

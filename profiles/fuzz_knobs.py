@@ -1,4 +1,4 @@
-"""One-off randomised check on the GPU box: random frames x random strategy (both surfaces) x random test-knob set against the
+"""One-off randomised check on the GPU box: random frames x random strategy (both surfaces) x random route-selector set against the
 oracle; prints every case that differs.  SEED / N from the environment.  python profiles/fuzz_knobs.py"""
 import os, sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
@@ -7,15 +7,16 @@ import underwater_image_enhancement_amd as uw
 from oracle import uwie_oracle as orc
 from test_gpu_fuzz import random_frame
 rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
-KNOBS = [{}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_LIN_NO_PREDICT": "1"}, {"UWIE_LIN_PREDICT_SHIFT": "3"}, {"UWIE_LIN_CAP": "24"},
-         {"UWIE_LIN_PREDICT_SHIFT": "300", "UWIE_RESTORE_STORE": "1"}, {"UWIE_SELECT_GENERIC": "1"}, {"UWIE_STREAMS": "2"}]
+KNOBS = [{}, {"restore_store": 1}, {"lin_no_predict": 1}, {"lin_predict_shift": 3}, {"lin_cap": 24},
+         {"lin_predict_shift": 300, "restore_store": 1}, {"select_generic": 1}, {"streams": 2}]  # uwie_set_tuning selectors
+DEFAULTS = {"restore_store": 0, "lin_no_predict": 0, "lin_predict_shift": 0, "lin_cap": 0, "select_generic": 0, "streams": 1}
 ES = orc.DictStrategyOracle
 names = ["strong_dehazing", "medium_dehazing", "light_enhancement", "clahe_enhancement", "histogram_equalization"]
 bad = tot = 0
 for i in range(int(os.environ.get("N", "150"))):
     u8 = random_frame(rng)
     knobs = KNOBS[rng.integers(len(KNOBS))]
-    for k, v in knobs.items(): os.environ[k] = v
+    uw.get_device(0).tune(**knobs)
     try:
         if rng.random() < float(os.environ.get("FUZZ_SIX_SHARE", "0.7")):
             k = int(rng.integers(1, 7))
@@ -35,7 +36,7 @@ for i in range(int(os.environ.get("N", "150"))):
                 got = np.ascontiguousarray(uw.EnhancementStrategies.apply_strategy(x, name, {})).view(np.uint64)
             what = name
     finally:
-        for k in knobs: del os.environ[k]
+        uw.get_device(0).tune(**DEFAULTS)
     d = np.abs(got.astype(np.int64) - want.astype(np.int64))
     tot += 1
     if d.max() > 0:

@@ -1,7 +1,7 @@
 """Guided-filter kernel variants side by side: time per launch and max |t - t_ref| against the exact-order kernel.
 
 usage: python profiles/gf_bench.py [H W B [k eps]]   (default 2160 3840 16 15 0.5)
-Variants are selected through the library's experiment knobs (UWIE_GF_PIPE, UWIE_GF_RING_FORCE), read per call.
+Variants are selected through the context's route selectors (uwie_set_tuning: gf_pipe, gf_split) and the mode argument.
 """
 import os
 import sys
@@ -25,10 +25,9 @@ gray = (255 * (field + 0.03 * torch.randn((B, H, W), device="cuda", generator=g)
 t0 = (1.0 - 0.5 * (field * 0.9 + 0.05 * torch.rand((B, H, W), device="cuda", generator=g))).clamp(0.1, 1.0).float().contiguous()
 
 
-def run(env, exact=False, reps=5):
-    for kk in ("UWIE_GF_PIPE", "UWIE_GF_RING_FORCE", "UWIE_GF_SPLIT", "UWIE_GF_XCD"):
-        os.environ.pop(kk, None)
-    os.environ.update(env)
+def run(sel, exact=False, reps=5):
+    dev.tune(gf_pipe=1, gf_split=1, gf_bands=0)
+    dev.tune(**sel)
     t = dev.guided_filter(gray, t0, k, eps, exact=exact)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,10 +44,9 @@ ref, ms_ref = run({}, exact=True, reps=1)
 ref = ref[:nb].clone()
 print(f"{H}x{W} x{B} k={k} eps={eps}")
 print(f"  exact-order kernels      {ms_ref:8.3f} ms")
-for name, env in (("round-1 wave (f64)", {"UWIE_GF_PIPE": "0"}), ("pipe, f64 ring in LDS", {"UWIE_GF_RING_FORCE": "0", "UWIE_GF_SPLIT": "0"}),
-                  ("pipe, f64 split ring", {"UWIE_GF_RING_FORCE": "0"}),
-                  ("  ... launch order as is", {"UWIE_GF_RING_FORCE": "0", "UWIE_GF_XCD": "0"}), ("pipe, fx32 ring", {"UWIE_GF_RING_FORCE": "1"})):
-    t, ms = run(env)
+for name, env, mode in (("LDS-tiled strip kernel", {"gf_pipe": 0}, False), ("pipe, f64 ring in LDS", {"gf_split": 0}, False),
+                        ("pipe, f64 split ring", {}, False), ("pipe, fx32 ring", {}, 2)):
+    t, ms = run(env, exact=mode)
     err = (t[:nb] - ref).abs().max().item()
     gbs = B * H * W * 13 / ms / 1e6
     print(f"  {name:24s} {ms:8.3f} ms   {gbs:7.1f} GB/s algorithmic   max|t - t_exact| = {err:.3e}")

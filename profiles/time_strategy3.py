@@ -13,8 +13,8 @@ def run(p, n=3):
     for _ in range(n): dev.enhance_u8(fr, p)
     torch.cuda.synchronize()
     return (time.time()-t)/n*1e3
-for env in ({}, {"UWIE_LIN_NO_PREDICT": "1"}):
-    os.environ.pop("UWIE_LIN_NO_PREDICT", None); os.environ.update(env)
+for env in ({"lin_predict3": 0}, {"lin_predict3": 1}):
+    dev.tune(**env)
     p = dev.params(_lib.SURFACE_SIX, 3, cast_correct=1)
     dev.profile(True); dev.enhance_u8(fr,p); rows=dev.profile_rows(); dev.profile(False)
     top=sorted(rows.items(), key=lambda kv:-kv[1][0])[:8]

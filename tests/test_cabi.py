@@ -143,3 +143,43 @@ def test_process_batch_log_rows_match_the_driver_columns():
     assert stats["processed_images"] == 2 and stats["total_images"] == 2
     with pytest.raises(ValueError):
         uw.process_batch(frames, ["only-one"], compute=fake)
+
+
+def test_no_entry_point_reads_the_environment():
+    """Route selectors live in the context (uwie_set_tuning); UWIE_<NAME> variables only seed them, once, in uwie_create
+    (round 2 read 25 variables per call).  The sources hold exactly one getenv call, in that seeding function."""
+    src = os.path.join(ROOT, "underwater_image_enhancement_amd", "csrc")
+    hits = []
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            text = re.sub(r"//.*", "", open(os.path.join(src, name)).read())
+            hits += [(name, m.start()) for m in re.finditer(r"\bgetenv\s*\(", text)]
+    assert [h[0] for h in hits] == ["api.hip"], hits
+    api = open(os.path.join(src, "api.hip")).read()
+    assert api.index("void tuning_from_env") < api.index("getenv(var)") < api.index("bool shape_ok")
+
+
+def test_division_free_ab_to_xz_equals_the_c_expression():
+    """k_fused.hip evaluates OpenCV's abToXZ_b entry without its three signed constant divisions (round 3):
+    truncation = floor after adding 840 to a negative numerator, floor(n / 841) = (n * 5106980) >> 32 for n < 1.49e6, the
+    cubic branch by 24-bit multiplies and shifts.  Same integers as the C expression for every argument the LAB2RGB path
+    can produce (i = ify +- the a / b term, -8145 .. 26868)."""
+    def c_div(a, b):
+        q = abs(a) // abs(b)
+        return q if (a >= 0) == (b > 0) else -q
+
+    def reference(i):
+        if i <= 3390:
+            return c_div(i * 108, 841) - c_div(c_div((1 << 14) * 16, 116) * 108, 841)
+        return c_div(c_div(i * i, 1 << 14) * i, 1 << 14)
+
+    def device(i):
+        t = i * 108
+        tp = (t + (840 if t < 0 else 0) + 841 * 1100) & 0xffffffff
+        lin = ((tp * 5106980) >> 32) - (1100 + 290)
+        u = i & 0xffffff  # v_mul_u32_u24 takes the low 24 bits of its operands
+        sq = ((u * u) & 0xffffffff) >> 14
+        cub = (((sq & 0xffffff) * u) & 0xffffffff) >> 14
+        return lin if i <= 3390 else cub
+
+    assert all(reference(i) == device(i) for i in range(-8145, 26869))

@@ -153,7 +153,7 @@ def test_dict_surface_matches_oracle(uw, orc, name):
                 assert dq.max() <= 1
 
 
-def test_dict_surface_select_and_store_modes(uw, orc, monkeypatch):
+def test_dict_surface_select_and_store_modes(uw, orc):
     """The dict surface's dehazing strategies take their float64 percentiles from the linear-digit selection on an image
     that is recomputed per sweep, with the target bins predicted from a sample (default); prediction off or missing,
     the stored-plane mode, the forced fallback to the generic key sweeps (tiny
@@ -169,14 +169,11 @@ def test_dict_surface_select_and_store_modes(uw, orc, monkeypatch):
         for tag, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd)):
             x = orc.normalise_u8(u8)
             want = ES.run(x, name, {})
-            for env in ({}, {"UWIE_RESTORE_STORE": "1"}, {"UWIE_LIN_CAP": "16"}, {"UWIE_LIN_CAP": "16", "UWIE_RESTORE_STORE": "1"},
-                        {"UWIE_SELECT_GENERIC": "1"}, {"UWIE_LIN_NO_PREDICT": "1"}, {"UWIE_LIN_PREDICT_SHIFT": "400"},
-                        {"UWIE_LIN_PREDICT_SHIFT": "400", "UWIE_RESTORE_STORE": "1"}):
-                for k, v in env.items():
-                    monkeypatch.setenv(k, v)
-                got = uw.EnhancementStrategies.apply_strategy(x, name, {})
-                for k in env:
-                    monkeypatch.delenv(k)
+            for env in ({}, {"restore_store": 1}, {"lin_cap": 16}, {"lin_cap": 16, "restore_store": 1},
+                        {"select_generic": 1}, {"lin_no_predict": 1}, {"lin_predict_shift": 400},
+                        {"lin_predict_shift": 400, "restore_store": 1}):
+                with uw.get_device().tuning(**env):
+                    got = uw.EnhancementStrategies.apply_strategy(x, name, {})
                 # float64 image: the fused guided filter's tolerance on t (1e-11) shows; identical after the float32 rounding
                 assert np.abs(got - want).max() < 1e-9 and np.array_equal(got.astype(np.float32), want.astype(np.float32)), (
                     name, tag, env, int((got.astype(np.float32) != want.astype(np.float32)).sum()))
@@ -368,8 +365,8 @@ def torch_from(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
-    """UWIE_STREAMS=2/3 (sub-batches on internal streams, joined on the caller's stream) must not change a byte, for
+def test_sub_batch_streams_and_profile_filter(uw):
+    """Tuning streams = 2 / 3 (sub-batches on internal streams, joined on the caller's stream) must not change a byte, for
     every surface; the profiler's name filter records only the named kernel."""
     from underwater_image_enhancement_amd import _lib
 
@@ -377,12 +374,11 @@ def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
     frames = rng.integers(0, 256, (7, 66, 98, 3), dtype=np.uint8)
     frames[2, :, :, 0] //= 3
     want = {k: uw.enhance(frames, strategy=k) for k in (1, 3, 5)}
-    for n in ("2", "3"):
-        monkeypatch.setenv("UWIE_STREAMS", n)
-        for k, w in want.items():
-            assert np.array_equal(uw.enhance(frames, strategy=k), w), (n, k)
-    monkeypatch.delenv("UWIE_STREAMS")
     dev = uw.get_device()
+    for n in (2, 3):
+        with dev.tuning(streams=n):
+            for k, w in want.items():
+                assert np.array_equal(uw.enhance(frames, strategy=k), w), (n, k)
     dev.profile(True)
     uw.enhance(frames, strategy=2)
     every = dev.profile_rows()
@@ -395,11 +391,11 @@ def test_sub_batch_streams_and_profile_filter(uw, monkeypatch):
     assert _lib.load().uwie_profile_filter(dev._ctx, None) == 0
 
 
-def test_select_paths_agree(uw, orc, monkeypatch):
+def test_select_paths_agree(uw, orc):
     """The percentile selection of strategies 1-3 has three routes: linear first digit with collected candidates (default),
     its fallback to the generic sweeps when a candidate list overflows (forced here with a tiny list capacity, and hit for
     real by a nearly constant frame), and the generic three-digit sweeps alone; strategies 1-2 run them either on the
-    the restored image recomputed per sweep (default) or on stored planes (UWIE_RESTORE_STORE=1).  All must give the
+    the restored image recomputed per sweep (default) or on stored planes (tuning restore_store).  All must give the
     oracle's bytes."""
     rng = np.random.default_rng(404)
     noisy = rng.integers(0, 256, (150, 210, 3), dtype=np.uint8)
@@ -414,25 +410,22 @@ def test_select_paths_agree(uw, orc, monkeypatch):
     big[:] = (60, 120, 200)
     big[::11, ::13] = rng.integers(0, 256, big[::11, ::13].shape, dtype=np.uint8)
     want_big = orc.enhance_u8(big, 2)
-    for store in ("0", "1"):
-        monkeypatch.setenv("UWIE_RESTORE_STORE", store)
-        for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd), ("wide", wide)):
-            for k in (1, 2, 3):
-                want = orc.enhance_u8(u8, k)
-                check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}, store={store}")
-                monkeypatch.setenv("UWIE_LIN_CAP", "16")
-                check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, store={store}")
-                monkeypatch.delenv("UWIE_LIN_CAP")
-                monkeypatch.setenv("UWIE_SELECT_GENERIC", "1")
-                check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
-                monkeypatch.delenv("UWIE_SELECT_GENERIC")
-                # the producer files the predicted windows (two, or strategy 3's four): off, still covering, missing
-                for knob, val in (("UWIE_LIN_NO_PREDICT", "1"), ("UWIE_LIN_PREDICT_SHIFT", "2"), ("UWIE_LIN_PREDICT_SHIFT", "400")):
-                    monkeypatch.setenv(knob, val)
-                    check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
-                    monkeypatch.delenv(knob)
-        check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")
-    monkeypatch.delenv("UWIE_RESTORE_STORE")
+    dev = uw.get_device()
+    for store in (0, 1):
+        with dev.tuning(restore_store=store):
+            for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd), ("wide", wide)):
+                for k in (1, 2, 3):
+                    want = orc.enhance_u8(u8, k)
+                    check_u8(uw.enhance(u8, strategy=k), want, f"default select, strategy {k} on {name}, store={store}")
+                    with dev.tuning(lin_cap=16):
+                        check_u8(uw.enhance(u8, strategy=k), want, f"forced fallback, strategy {k} on {name}, store={store}")
+                    with dev.tuning(select_generic=1):
+                        check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
+                    # the producer files the predicted windows (two, or strategy 3's four): off, still covering, missing
+                    for knob, val in (("lin_no_predict", 1), ("lin_predict_shift", 2), ("lin_predict_shift", 400), ("lin_predict3", 1)):
+                        with dev.tuning(**{knob: val}):
+                            check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
+            check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")
     batch = np.stack([noisy[:120, :200], flatish[:120, :200], noisy[30:150, 10:210]])
     assert np.array_equal(uw.enhance(batch, strategy=2), np.stack([uw.enhance(f, strategy=2) for f in batch]))
 

@@ -206,14 +206,14 @@ def test_transmission_init_and_guided_filter(dev, orc, frames):
 
 @pytest.mark.parametrize("k", [15, 20, 10])
 @pytest.mark.parametrize("shape,bands", [((260, 700), 2), ((181, 256), 1), ((333, 490), 3), ((64, 300), 1), ((75, 128), 2)])
-def test_split_ring_guided_filter(dev, orc, monkeypatch, shape, bands, k):
+def test_split_ring_guided_filter(dev, orc, shape, bands, k):
     """The split-ring kernel (a in LDS, b in registers, steady loop unrolled over the ring period) for the reference's three
     window widths (six_stadigy.py:234,245,255; config.py:29-53).  k = 15: every row -- row indices are reflected at the top
     and bottom borders, a last period that runs past the image stores nothing there.  k = 20 / 10 (round 3): the window is
     not symmetric, so the split kernel takes the whole bands between row k and row H - (k - 2) and the general kernel the
     rows above and below; the raw rows of k = 20 are re-read instead of kept in registers.
-    Production takes it for large batches only (4K x 16 and up: the full-size tests and bench.py); here UWIE_GF_BANDS
-    forces it on small frames so that the oracle comparison covers every part of it: edge strips (reflected columns,
+    Production takes it for large batches only (4K x 16 and up: the full-size tests and bench.py); here the gf_bands
+    selector forces it on small frames so that the oracle comparison covers every part of it: edge strips (reflected columns,
     mirrored a/b), interior strips, a ragged last strip, several bands (the last one shorter), heights that are no multiple
     of the ring period, frames barely taller than four windows (or shorter: then the general kernel alone runs).  Same
     tolerance as every float64 ring: 1e-11 absolute on t."""
@@ -223,17 +223,17 @@ def test_split_ring_guided_filter(dev, orc, monkeypatch, shape, bands, k):
     gray = rng.integers(0, 256, (B, H, W), dtype=np.uint8)
     gray[1] = (np.add.outer(np.arange(H), 2 * np.arange(W)) % 256).astype(np.uint8)
     t0 = np.clip(rng.random((B, H, W), dtype=np.float32), 0.1, 1.0)
-    monkeypatch.setenv("UWIE_GF_BANDS", str(bands))
-    for eps in (0.5, 1e-3):
-        got = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), k, eps, exact=False).cpu().numpy()
-        for b in range(B):
-            want = np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], k, eps), 0.1, 1.0)
-            err = np.abs(got[b] - want).max()
-            assert err <= 1e-11, (k, shape, bands, eps, b, err)
-    monkeypatch.setenv("UWIE_GF_SPLIT", "0")  # the general kernel alone gives the same answer to the same tolerance
-    alone = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), k, 0.5, exact=False).cpu().numpy()
-    assert np.abs(alone - np.stack([np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], k, 0.5), 0.1, 1.0)
-                                    for b in range(B)])).max() <= 1e-11
+    with dev.tuning(gf_bands=bands):
+        for eps in (0.5, 1e-3):
+            got = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), k, eps, exact=False).cpu().numpy()
+            for b in range(B):
+                want = np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], k, eps), 0.1, 1.0)
+                err = np.abs(got[b] - want).max()
+                assert err <= 1e-11, (k, shape, bands, eps, b, err)
+        with dev.tuning(gf_split=0):  # the general kernel alone gives the same answer to the same tolerance
+            alone = dev.guided_filter(dev.tensor(gray), dev.tensor(t0), k, 0.5, exact=False).cpu().numpy()
+        assert np.abs(alone - np.stack([np.clip(orc.guided_filter(gray[b].astype(np.float64) / 255.0, t0[b], k, 0.5), 0.1, 1.0)
+                                        for b in range(B)])).max() <= 1e-11
 
 
 @pytest.mark.parametrize("k", [15, 20, 10, 7])

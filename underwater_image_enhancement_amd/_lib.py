@@ -64,6 +64,8 @@ SIGNATURES = {
     "uwie_profile_collect": [_VP],
     "uwie_profile_row": [_VP, _I, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_D), ctypes.POINTER(_I)],
     "uwie_params_init": [_PP, _I, _I],
+    "uwie_set_tuning": [_VP, ctypes.c_char_p, _I],
+    "uwie_get_tuning": [_VP, ctypes.c_char_p, ctypes.POINTER(_I)],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
     "uwie_workspace_bytes_all": [_I, _I, _I, _VP],
     "uwie_workspace_bytes_float": [_I, _I, _I, _PP, _I],

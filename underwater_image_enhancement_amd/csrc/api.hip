@@ -11,6 +11,11 @@
 namespace uwie {
 
 static thread_local char g_err[512] = "";
+static thread_local uwie_ctx *g_ctx = nullptr;  // context of the entry point running on this thread
+static const Tuning g_default_tuning{};
+
+const Tuning &tune() { return g_ctx ? g_ctx->tune : g_default_tuning; }
+uwie_ctx *current_ctx() { return g_ctx; }
 
 void set_error(const char *fmt, ...)
 {
@@ -21,6 +26,56 @@ void set_error(const char *fmt, ...)
 }
 
 namespace {
+
+// Every exported function that launches work runs inside one of these: the context's device becomes current (kernels,
+// events and helper streams belong to it) and is put back afterwards, and the context's tuning is what tune() answers.
+class CallScope {
+public:
+    explicit CallScope(uwie_ctx *ctx) : prev_ctx_(g_ctx)
+    {
+        g_ctx = ctx;
+        if (ctx && hipGetDevice(&prev_dev_) == hipSuccess && prev_dev_ != ctx->device) {
+            if (hipSetDevice(ctx->device) == hipSuccess) switched_ = true;
+            else ok_ = false;
+        }
+    }
+    ~CallScope()
+    {
+        if (switched_) (void)hipSetDevice(prev_dev_);
+        g_ctx = prev_ctx_;
+    }
+    CallScope(const CallScope &) = delete;
+    bool ok() const { return ok_; }
+
+private:
+    uwie_ctx *prev_ctx_;
+    int prev_dev_ = -1;
+    bool switched_ = false, ok_ = true;
+};
+#define UWIE_SCOPE(ctx)                                                       \
+    CallScope _uwie_scope(ctx);                                               \
+    if (!_uwie_scope.ok()) {                                                  \
+        set_error("cannot make device %d current", (ctx)->device);           \
+        return UWIE_E_HIP;                                                    \
+    }
+
+struct KnobName { const char *name; int Tuning::*field; };
+const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::gf_split}, {"gf_bands", &Tuning::gf_bands},
+                           {"select_generic", &Tuning::select_generic}, {"restore_store", &Tuning::restore_store},
+                           {"lin_predict3", &Tuning::lin_predict3}, {"lin_cap", &Tuning::lin_cap},
+                           {"lin_no_predict", &Tuning::lin_no_predict}, {"lin_predict_shift", &Tuning::lin_predict_shift},
+                           {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass}};
+
+void tuning_from_env(Tuning *t)  // uwie_create only
+{
+    for (const KnobName &k : kKnobs) {
+        char var[64] = "UWIE_";
+        size_t n = 5;
+        for (const char *c = k.name; *c && n + 1 < sizeof var; ++c) var[n++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        var[n] = 0;
+        if (const char *e = getenv(var)) t->*(k.field) = atoi(e);
+    }
+}
 
 bool shape_ok(int B, int H, int W)
 {
@@ -136,10 +191,8 @@ int stage_guided(uwie_ctx *ctx, const Pipe &P, Shape s, const uwie_params *p, hi
             return UWIE_OK;
         }
     }
-    // fixed-point a/b ring: only with the pre-clipped transmission of the six_stadigy surface (0.1 <= t0 <= 1 bounds a, b).
-    // UWIE_GF_RING=1 (read per call, experiments) forces it like inter_dtype = UWIE_INTER_FX32.
-    const char *env_ring = getenv("UWIE_GF_RING");
-    const bool fx = p->surface == UWIE_SURFACE_SIX && (p->inter_dtype == UWIE_INTER_FX32 || (env_ring && atoi(env_ring) == 1));
+    // fixed-point a/b ring: only with the pre-clipped transmission of the six_stadigy surface (0.1 <= t0 <= 1 bounds a, b)
+    const bool fx = p->surface == UWIE_SURFACE_SIX && p->inter_dtype == UWIE_INTER_FX32;
     if (!p->gf_exact) UWIE_TRY(launch_guided_fast(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, &handled, st, fx));
     if (!handled) UWIE_TRY(launch_guided(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, P.t, P.scratch, st));
     return UWIE_OK;
@@ -187,11 +240,10 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     SelectPlan plan;
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
     // the restored image is clipped to [0, 1]: linear first digit, one collecting sweep (k_select.hip, select_lin_*);
-    // UWIE_SELECT_GENERIC=1 keeps the three-digit key sweeps
-    const char *env_generic = getenv("UWIE_SELECT_GENERIC");  // read per call
+    // tuning select_generic keeps the three-digit key sweeps
     const RestoreSrc src{d_in, kind, P.A, P.t, t_is_f32};
     bool recompute = false;
-    if (env_generic && atoi(env_generic) == 1) {
+    if (tune().select_generic) {
         UWIE_TRY(select_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, P.F, plan.ghist, st, false, nullptr, nullptr, t_is_f32));
         UWIE_TRY(select_run(plan, P.F, 1, s, true, st));
@@ -199,16 +251,14 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // Strategies 1 and 2 never store the restored image: the histogram sweep (which also files the elements of the
         // predicted target bins, select_lin_begin) and the stretch each recompute it from the frame and t (restore.h:
         // 11 + 14 bytes per pixel instead of 23 + 15, and no collecting sweep).  P.F is only written for images whose
-        // selection falls back to the generic sweeps.  UWIE_RESTORE_STORE=1 keeps the stored planes (4K x 64: 17.9 vs
-        // 17.5 ms per step).
-        const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call: the tests compare both modes
-        recompute = k != 3 && !(env_store && atoi(env_store) == 1);
+        // selection falls back to the generic sweeps.  Tuning restore_store keeps the stored planes (4K x 64: 17.9 vs
+        // 17.5 ms per step, round 2); the tests compare both modes.
+        recompute = k != 3 && !tune().restore_store;
         // Strategy 3 keeps the planes (its tail reads them), so the exact target bins can be collected from them by one
         // streaming sweep: no predicted windows there -- its percentiles (20 / 85 / 2 / 98) sit where the bins are full and
         // four windows made the restore sweep 2.9 ms at 4K x 16 against 0.65 + 0.35 for sweep + collection.
-        // UWIE_LIN_PREDICT3=1 (read per call) brings the windows back.
-        const char *env_p3 = getenv("UWIE_LIN_PREDICT3");
-        const bool predict = k != 3 || (env_p3 && atoi(env_p3) == 1);
+        // Tuning lin_predict3 brings the windows back.
+        const bool predict = k != 3 || tune().lin_predict3;
         UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, predict ? &src : nullptr));
         UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
                                             &plan, t_is_f32));
@@ -247,20 +297,18 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
     SelectPlan plan;
     const double q[2] = {p->L_low, p->L_high};
     // the recovered image is clipped to [0, 1]: linear first digit, one collecting sweep (select_lin_*64);
-    // UWIE_SELECT_GENERIC=1 keeps the six-digit key sweeps
-    const char *env_generic = getenv("UWIE_SELECT_GENERIC");
+    // tuning select_generic keeps the six-digit key sweeps
     const RestoreSrc src{d_in, nullptr, P.A, P.t};
     bool recompute = false;
-    if (env_generic && atoi(env_generic) == 1) {
+    if (tune().select_generic) {
         UWIE_TRY(select_begin64(s, q, 2, P.scratch, st, &plan));
         UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, P.F64, plan.ghist, st));
         UWIE_TRY(select_run64(plan, P.F64, 1, s, true, st));
     } else {
         // the float64 image (24 B/px) is not stored either: histogram sweep, collecting sweep and stretch recompute it
         // from the frame and t (11 B/px each); P.F64 only serves images that fall back to the generic sweeps.
-        // UWIE_RESTORE_STORE=1 keeps the stored planes.
-        const char *env_store = getenv("UWIE_RESTORE_STORE");  // read per call
-        recompute = !(env_store && atoi(env_store) == 1);
+        // Tuning restore_store keeps the stored planes.
+        recompute = !tune().restore_store;
         UWIE_TRY(select_lin_begin64(s, q, 2, P.scratch, st, &plan, &src));
         UWIE_TRY(launch_recover64_planar_hist(d_in, P.A, P.t, s, recompute ? nullptr : P.F64, plan.ghist, st, true, nullptr,
                                               &plan));
@@ -463,6 +511,7 @@ int uwie_create(int device, uwie_ctx **out_ctx)
     ctx->aux_ready = false;
     ctx->prof = prof_create();
     ctx->device = device;
+    tuning_from_env(&ctx->tune);
     LabTables *lab = new LabTables();
     CastTables *cast = new CastTables();
     build_lab_tables(lab);
@@ -529,6 +578,30 @@ int uwie_profile_row(uwie_ctx *ctx, int i, const char **name, double *total_ms, 
     return prof_row(ctx->prof, i, name, total_ms, calls);
 }
 
+int uwie_set_tuning(uwie_ctx *ctx, const char *name, int value)
+{
+    UWIE_REQUIRE(ctx && name, "set_tuning: NULL pointer");
+    for (const KnobName &k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) {
+            ctx->tune.*(k.field) = value;
+            return UWIE_OK;
+        }
+    set_error("set_tuning: unknown selector '%s'", name);
+    return UWIE_E_INVALID;
+}
+
+int uwie_get_tuning(uwie_ctx *ctx, const char *name, int *value)
+{
+    UWIE_REQUIRE(ctx && name && value, "get_tuning: NULL pointer");
+    for (const KnobName &k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) {
+            *value = ctx->tune.*(k.field);
+            return UWIE_OK;
+        }
+    set_error("get_tuning: unknown selector '%s'", name);
+    return UWIE_E_INVALID;
+}
+
 int uwie_params_init(uwie_params *p, int surface, int strategy)
 {
     UWIE_REQUIRE(p != nullptr, "params is NULL");
@@ -570,14 +643,13 @@ int uwie_params_init(uwie_params *p, int surface, int strategy)
     return UWIE_E_INVALID;
 }
 
-// How many sub-batches uwie_enhance_u8 runs on separate streams: UWIE_STREAMS=2..4 (read on every call), default 1.
-// Two streams shorten a 4K x 64 step by 4.5 % (20.8 -> 19.9 ms) because issue-bound and memory-bound stages of different
-// sub-batches overlap; it is opt-in because overlapped kernels no longer have a per-kernel duration that means anything
-// (bench.py's roofline line and rocprofv3's averages both read 1.8x for the guided filter).
+// How many sub-batches uwie_enhance_u8 runs on separate streams: tuning `streams` = 2..4, default 1.
+// Two streams shorten a 4K x 64 step by ~3 % because issue-bound and memory-bound stages of different sub-batches overlap;
+// it is opt-in because overlapped kernels no longer have a per-kernel duration that means anything (bench.py's roofline
+// line and rocprofv3's averages both read 1.8x for the guided filter).
 static int enhance_split(int batch)
 {
-    const char *env_split = getenv("UWIE_STREAMS");
-    const int n = env_split ? std::min(std::max(atoi(env_split), 1), 4) : 1;
+    const int n = std::min(std::max(tune().streams, 1), 4);
     return batch >= n ? n : 1;
 }
 
@@ -588,9 +660,9 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
     Carver c(nullptr);
     carve_pipe(c, s, p);
     size_t pipe = c.total();
-    // uwie_enhance_u8 may run the batch as sub-batches on separate streams, each with its own slice
-    const int nsplit = enhance_split(batch);
-    if (nsplit > 1) {
+    // uwie_enhance_u8 may run the batch as up to four sub-batches on separate streams (tuning `streams`), each with its own
+    // slice: sized for whichever split is the largest, so the answer does not depend on a context
+    for (int nsplit = 2; nsplit <= 4 && nsplit <= batch; ++nsplit) {
         size_t off = 0;
         for (int i = 0; i < nsplit; ++i) {
             Carver ci(nullptr);
@@ -634,7 +706,7 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
                     const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && (d_out_u8 || d_out_f32), "enhance: NULL context or image pointer");
-    UWIE_HIP_CHECK(hipSetDevice(ctx->device));  // kernels, events and helper streams belong to the context's device
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_TRY(check_params(p));
     const Shape s{batch, H, W};
@@ -656,7 +728,7 @@ int uwie_enhance_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, float
             b0 += cnt[i];
             Carver ci(static_cast<char *>(d_workspace) + off);
             Ps[i] = carve_pipe(ci, Shape{cnt[i], H, W}, p);
-            if (off + ci.total() > workspace_bytes) fits_ws = false;  // (UWIE_STREAMS may have changed since the sizing call)
+            if (off + ci.total() > workspace_bytes) fits_ws = false;  // (a caller that sized for another parameter set)
             off = (off + ci.total() + 255) & ~(size_t)255;
         }
         if (fits_ws) {
@@ -699,7 +771,7 @@ int uwie_enhance_u8_f64(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, d
                         const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_out_f64, "enhance_f64: NULL context or image pointer");
-    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_TRY(check_params(p));
     UWIE_REQUIRE(p->surface == UWIE_SURFACE_DICT, "enhance_f64: float64 images are the dict surface's (ES:247,307,345)");
@@ -723,7 +795,7 @@ int uwie_enhance_f32(uwie_ctx *ctx, const float *d_img, uint8_t *d_out_u8, float
                      const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && (d_out_u8 || d_out_f32 || d_out_f64), "enhance_f32: NULL context or image pointer");
-    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_TRY(check_params(p));
     const Shape s{batch, H, W};
@@ -741,7 +813,7 @@ int uwie_enhance_f64(uwie_ctx *ctx, const double *d_img, uint8_t *d_out_u8, doub
                      const uwie_params *p, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && (d_out_u8 || d_out_f64), "enhance_f64: NULL context or image pointer");
-    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_TRY(check_params(p));
     UWIE_REQUIRE(p->surface == UWIE_SURFACE_DICT, "enhance_f64: float64 images are the dict surface's (six_stadigy.py works on float32, S6:406)");
@@ -755,6 +827,7 @@ int uwie_enhance_f64(uwie_ctx *ctx, const double *d_img, uint8_t *d_out_u8, doub
 int uwie_color_correct_f32(uwie_ctx *ctx, const float *d_img, const int32_t *d_kind, float *d_out, int batch, int H, int W, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && d_kind && d_out, "color_correct_f32: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     return launch_float_prepare<float>(d_img, d_kind, d_out, nullptr, Shape{batch, H, W}, (hipStream_t)stream);
 }
@@ -762,6 +835,7 @@ int uwie_color_correct_f32(uwie_ctx *ctx, const float *d_img, const int32_t *d_k
 int uwie_cast_classify_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, int W, int32_t *d_kind, float *d_mean_rgb, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && (d_kind || d_mean_rgb), "cast_classify_f32: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     return launch_float_cast_classify<float>(d_img, Shape{batch, H, W}, d_kind, d_mean_rgb, (hipStream_t)stream);
 }
@@ -770,7 +844,7 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
                         const uwie_params *p6, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_out_u8, "enhance_all: NULL context or image pointer");
-    UWIE_HIP_CHECK(hipSetDevice(ctx->device));
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     uwie_params P6[6];
     for (int k = 0; k < 6; ++k) {
@@ -808,6 +882,7 @@ int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int b
                           const float *d_params, int flags, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && d_out && d_params, "diff_enhance: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE((flags & ~3) == 0, "diff_enhance: flags are UWIE_DIFF_OMEGA | UWIE_DIFF_GAMMA");
     const Shape s{batch, H, W};
@@ -823,6 +898,7 @@ int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_featur
                              void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_features, "extract_features: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(features_ws_bytes(s));
@@ -833,6 +909,7 @@ int uwie_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, 
                         const double *weights8, double *d_scores, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_u8 && d_scores, "quality_scores: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(gray_shift == 14 || gray_shift == 15, "gray_shift must be 14 or 15");
     static const double kDefault[8] = {0.20, 0.20, 0.15, 0.15, 0.10, 0.10, 0.05, 0.05};  // quality_assessment.py:229-238
@@ -848,6 +925,7 @@ int uwie_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int
                        void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && (d_kind || d_mean_rgb), "cast_classify: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(cast_ws_bytes(s));
@@ -858,6 +936,7 @@ int uwie_normalise_correct(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
                            int W, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_out_f32, "normalise_correct: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     return launch_normalise_correct(d_in, d_kind, d_out_f32, Shape{batch, H, W}, (hipStream_t)stream);
 }
@@ -867,6 +946,7 @@ int uwie_atmospheric_light(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
                            void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_A && p, "atmospheric_light: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(p->min_size >= 1 && (p->gray_shift == 14 || p->gray_shift == 15), "atmospheric_light: bad params");
     const Shape s{batch, H, W};
@@ -882,6 +962,7 @@ int uwie_transmission_init(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_
                            int W, const uwie_params *p, float *d_t0, uint8_t *d_gray, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_A && p && (d_t0 || d_gray), "transmission_init: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     hipStream_t st = (hipStream_t)stream;
@@ -895,6 +976,7 @@ int uwie_box_filter_f64(uwie_ctx *ctx, const double *d_src, double *d_dst, int b
                         void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_src && d_dst, "box_filter: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "box_filter: ksize out of range");
     const Shape s{batch, H, W};
@@ -906,6 +988,7 @@ int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, 
                        double eps, int exact, double *d_t, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_gray && d_t0 && d_t, "guided_filter: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(ksize >= 1 && ksize <= 1024, "guided_filter: ksize out of range");
     const Shape s{batch, H, W};
@@ -932,6 +1015,7 @@ int uwie_restore(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, cons
                  int batch, int H, int W, float *d_out_f32, void *stream)
 {
     UWIE_REQUIRE(ctx && d_in && d_A && d_t && d_out_f32, "restore: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     return launch_restore(d_in, d_kind, d_A, d_t, Shape{batch, H, W}, d_out_f32, (hipStream_t)stream);
 }
@@ -940,6 +1024,7 @@ int uwie_percentiles_f32(uwie_ctx *ctx, const float *d_img, int batch, int H, in
                          float *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && q_percent && d_out, "percentiles: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     UWIE_CHECK_WS(select_ws_bytes(s));
@@ -950,6 +1035,7 @@ int uwie_stretch_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch,
                      double hi_percent, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && d_out, "stretch: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     Carver c(d_workspace);
@@ -965,6 +1051,7 @@ int uwie_stretch_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch,
 int uwie_gamma_f32(uwie_ctx *ctx, const float *d_img, float *d_out, size_t n, double g, int mode, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && d_out, "gamma: NULL pointer");
+    UWIE_SCOPE(ctx);
     return launch_gamma_f32(d_img, d_out, n, g, mode, (hipStream_t)stream);
 }
 
@@ -972,6 +1059,7 @@ int uwie_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, i
                    int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_img && d_out, "clahe: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(tiles_x >= 1 && tiles_y >= 1 && tiles_x * tiles_y <= 4096, "clahe: bad tile grid");
     const Shape s{batch, H, W};
@@ -982,6 +1070,7 @@ int uwie_clahe_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, i
 int uwie_rgb2gray_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_gray, size_t npixels, int gray_shift, void *stream)
 {
     UWIE_REQUIRE(ctx && d_rgb && d_gray, "rgb2gray: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_REQUIRE(gray_shift == 14 || gray_shift == 15, "gray_shift must be 14 or 15");
     return launch_rgb2gray_u8(d_rgb, d_gray, npixels, gray_shift, (hipStream_t)stream);
 }
@@ -989,12 +1078,14 @@ int uwie_rgb2gray_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_gray, size_
 int uwie_rgb2lab_u8(uwie_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_lab, size_t npixels, void *stream)
 {
     UWIE_REQUIRE(ctx && d_rgb && d_lab, "rgb2lab: NULL pointer");
+    UWIE_SCOPE(ctx);
     return launch_rgb2lab_u8(ctx, d_rgb, d_lab, npixels, (hipStream_t)stream);
 }
 
 int uwie_lab2rgb_u8(uwie_ctx *ctx, const uint8_t *d_lab, uint8_t *d_rgb, size_t npixels, void *stream)
 {
     UWIE_REQUIRE(ctx && d_lab && d_rgb, "lab2rgb: NULL pointer");
+    UWIE_SCOPE(ctx);
     return launch_lab2rgb_u8(ctx, d_lab, d_rgb, npixels, (hipStream_t)stream);
 }
 
@@ -1002,6 +1093,7 @@ int uwie_clahe_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out, int bat
                   int tiles_x, int tiles_y, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_plane && d_out, "clahe_u8: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     UWIE_REQUIRE(tiles_x >= 1 && tiles_y >= 1 && tiles_x * tiles_y <= 4096, "clahe: bad tile grid");
     const Shape s{batch, H, W};
@@ -1013,6 +1105,7 @@ int uwie_canny_u8(uwie_ctx *ctx, const uint8_t *d_gray, uint8_t *d_edges, int ba
                   void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_gray && d_edges, "canny: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     if (low > high) { const int t = low; low = high; high = t; }
     const Shape s{batch, H, W};
@@ -1029,6 +1122,7 @@ int uwie_equalize_hist_u8(uwie_ctx *ctx, const uint8_t *d_plane, uint8_t *d_out,
                           void *d_workspace, size_t workspace_bytes, void *stream)
 {
     UWIE_REQUIRE(ctx && d_plane && d_out, "equalize_hist: NULL pointer");
+    UWIE_SCOPE(ctx);
     UWIE_CHECK_SHAPE(batch, H, W);
     const Shape s{batch, H, W};
     UWIE_CHECK_WS((size_t)batch * 256 + 256);

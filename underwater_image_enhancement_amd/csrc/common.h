@@ -81,8 +81,32 @@ private:
 
 }  // namespace uwie
 
+namespace uwie {
+// Route selectors of one context.  The defaults are what ships and what uwie_params cannot express: which of several
+// equivalent routes a stage takes (tests force the fallback routes through uwie_set_tuning; profiles/ scripts compare
+// them).  Environment variables UWIE_<NAME> are read ONCE, in uwie_create -- never per call.
+struct Tuning {
+    int gf_pipe = 1;            // guided filter: wavefront kernels of k_guided_pipe.hip (0: the LDS-tiled strip kernel)
+    int gf_split = 1;           // ... their split-ring form for large jobs (0: the general kernel alone)
+    int gf_bands = 0;           // ... bands per strip (0: chosen from the job's size)
+    int select_generic = 0;     // percentile selection: the three-digit key sweeps alone
+    int restore_store = 0;      // strategies 1-2 / dict dehazing: keep the restored image in planes instead of recomputing it
+    int lin_predict3 = 0;       // strategy 3: predicted windows as for strategies 1-2
+    int lin_cap = 0;            // candidate list capacity (0: default; small values force the overflow fallback)
+    int lin_no_predict = 0;     // no predicted windows: always the collecting sweep
+    int lin_predict_shift = 0;  // predicted windows moved by this many bins (large: every prediction misses)
+    int streams = 1;            // uwie_enhance_u8: sub-batches on this many internal streams (1 .. 4)
+    int canny_prepass = 1;      // quadtree: the streaming "any strong pixel?" pass before Canny
+};
+const Tuning &tune();  // tuning of the context whose entry point is running on this host thread (defaults outside one)
+uwie_ctx *current_ctx();
+}  // namespace uwie
+
 struct uwie_ctx {
     int device;
+    uwie::Tuning tune;
+    bool attr_q_tail = false;   // > 64 KB LDS attributes set on this context's device: k_q_tail,
+    int attr_gf_fast = 0;       // k_guided_fast<TH> (bit TH)
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;
     uwie::Profiler *prof;
@@ -175,9 +199,6 @@ int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, vo
 int launch_guided(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, void *ws,
                   hipStream_t st);
 
-// k_guided_wave.hip: barrier-free wavefront-per-strip guided filter for k in {10, 15, 20}; *handled = 0 -> not taken
-int launch_guided_wave(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, double *d_t, int *handled,
-                       hipStream_t st);
 bool guided_fast_handles(Shape s, int k);
 // k_guided_fast.hip: fused float64 guided filter (free summation order); *handled = 0 -> use launch_guided
 // ring_fx: the caller guarantees 0.1 <= t0 <= 1 (pre-clipped transmission) and accepts the fixed-point a/b ring

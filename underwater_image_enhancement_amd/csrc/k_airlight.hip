@@ -874,7 +874,6 @@ size_t airlight_ws_bytes(Shape s)
 int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int min_size,
                     float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift)
 {
-    (void)ctx;
     Carver c(ws);
     LevelBufs L = carve_level(c, s);
     void *canny_ws = c.take<char>(canny_ws_bytes(s));
@@ -887,14 +886,7 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
     UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(L.edges, 0, sizeof(uint32_t) * nreg, st));
-    static const bool use_tail = [] {
-        const char *e = getenv("UWIE_Q_TAIL");
-        return !(e && e[0] == '0');
-    }();
-    static const bool fuse_gray = [] {
-        const char *e = getenv("UWIE_Q_GRAY_FUSE");
-        return !(e && e[0] == '0');
-    }();
+    constexpr bool use_tail = true, fuse_gray = true;  // (the small levels in one launch; level 0 writes the gray plane)
     bool gray_pending = make_gray_shift != 0;
     {
         const bool level0_launched = s.H > min_size && s.W > min_size &&
@@ -933,14 +925,11 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
     }
     // the remaining levels (none when the walk above already reached the leaves) and the leaf's brightest pixel
     {
-        // more than 64 KB of LDS has to be asked for, once per device (a process may hold contexts on several)
-        static bool attr_set[64] = {};
-        int dev = 0;
-        UWIE_HIP_CHECK(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        // more than 64 KB of LDS has to be asked for, once per context (= per device: a process may hold several)
+        if (!ctx || !ctx->attr_q_tail) {
             UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_q_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                4 * kTailQuadBytes));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            if (ctx) ctx->attr_q_tail = true;
         }
     }
     UWIE_LAUNCH(k_q_tail, dim3(B), dim3(256 * kTailSub), 4 * kTailQuadBytes, st, d_in, d_kind, d_gray, L.blk, s.H, s.W, level, min_size,

@@ -642,9 +642,8 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     if (d_count && !count_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
     // Pre-pass (edge counts only: the standalone edge map keeps the single pass): regions without a pixel above the high
-    // threshold have no edges.  UWIE_CANNY_PREPASS=0 (read per call) disables it.
-    const char *env_pre = getenv("UWIE_CANNY_PREPASS");
-    if (d_edges || nreg > s.B * 4 || (env_pre && atoi(env_pre) == 0)) bufs.strong = nullptr;
+    // threshold have no edges.  Tuning canny_prepass = 0 disables it.
+    if (d_edges || nreg > s.B * 4 || !tune().canny_prepass) bufs.strong = nullptr;
     if (bufs.strong) {
         UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
         if (max_cols >= 8) {  // the streaming pre-pass loads 8 bytes per row

@@ -1097,8 +1097,7 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 {
     // 24.6 KB of LDS per block: six blocks per CU, 1536 resident on the chip.  Enough blocks for several full rounds
     // (2048 blocks were 1.33 rounds: a third of the chip idle for half the kernel).
-    static const char *env_nb = getenv("UWIE_RESTORE_BLOCKS");
-    int nblk = env_nb ? atoi(env_nb) : cdiv(12288, s.B);  // 4K x 64: 32 per frame 2.79 ms, 96: 2.52, 192: 2.43, 384: 2.47
+    int nblk = cdiv(12288, s.B);  // 4K x 64: 32 per frame 2.79 ms, 96: 2.52, 192: 2.43, 384: 2.47 (round 1)
     // (a block clears and flushes 6 K counters: small batches get fewer, longer blocks; 4K x 16: 768 per frame 0.62 ms, 192: 0.53)
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
@@ -1194,8 +1193,7 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     UWIE_LAUNCH_CHECK();
     // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
     const int cells = (tx + 1) * (ty + 1);
-    static const char *env_nc = getenv("UWIE_CLAHE_CHUNKS");
-    int nchunk = env_nc ? atoi(env_nc) : cdiv(25920, cells * s.B);  // ~12 rounds of the 2048 resident blocks
+    int nchunk = cdiv(25920, cells * s.B);  // ~12 rounds of the 2048 resident blocks
     nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
     const auto k_clahe_apply_u8 = k_clahe_apply_out<false, false>;  // (names as the profiler reports them)
     const auto k_clahe_apply_f32 = k_clahe_apply_out<false, true>;

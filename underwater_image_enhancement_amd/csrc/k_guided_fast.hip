@@ -317,11 +317,12 @@ __global__ void __launch_bounds__(kFastThreads) k_guided_fast(const uint8_t *__r
 template <int TH>
 int launch_th(const uint8_t *d_gray, const float *d_t0, Shape s, const FastGeom &g, double eps, double *d_t, hipStream_t st)
 {
-    static thread_local size_t attr_set = 0;
-    if (g.lds_bytes > 64 * 1024 && g.lds_bytes > attr_set) {
+    // more than 64 KB of LDS has to be asked for: once per context (= device) and kernel, for the most a CU has
+    uwie_ctx *ctx = current_ctx();
+    if (g.lds_bytes > 64 * 1024 && !(ctx && (ctx->attr_gf_fast & TH))) {
         UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_guided_fast<TH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-        attr_set = g.lds_bytes;
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (ctx) ctx->attr_gf_fast |= TH;
     }
     UWIE_LAUNCH(k_guided_fast<TH>, dim3(cdiv(s.W, kStripW), s.B), dim3(kFastThreads), g.lds_bytes, st, d_gray, d_t0, d_t, g,
                 eps);
@@ -339,9 +340,9 @@ bool fits(const FastGeom &g, int TH)
 
 }  // namespace
 
-// Whether launch_guided_fast will take this (shape, window) with one of the k_guided_fast<TH> kernels (k_guided_wave is
-// tried first but every shape it takes is also taken here); if not, the exact-order path and its six float64 planes of
-// workspace are needed.
+// Whether launch_guided_fast will take this (shape, window) with one of the k_guided_fast<TH> kernels (the wavefront kernels
+// of k_guided_pipe.hip are tried first, but every shape they take is also taken here); if not, the exact-order path and its
+// six float64 planes of workspace are needed.
 bool guided_fast_handles(Shape s, int k)
 {
     return fits(make_fast_geom(s, k, 8), 8) || fits(make_fast_geom(s, k, 4), 4) || fits(make_fast_geom(s, k, 2), 2);
@@ -353,18 +354,10 @@ int launch_guided_fast(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
                        hipStream_t st, bool ring_fx)
 {
     *handled = 0;
-    // software-pipelined wavefront kernel (k_guided_pipe.hip) first; UWIE_GF_PIPE=0 keeps the round-1 kernels
-    const char *env_pipe = getenv("UWIE_GF_PIPE");  // read per call: the tests compare the kernels
-    if (!(env_pipe && atoi(env_pipe) == 0)) {
-        const char *env_force = getenv("UWIE_GF_RING_FORCE");  // experiments only (profiles/gf_bench.py): 0 / 1
-        if (env_force) ring_fx = atoi(env_force) == 1;
+    // software-pipelined wavefront kernels (k_guided_pipe.hip) first; tuning gf_pipe = 0 keeps the LDS-tiled strip kernel
+    if (tune().gf_pipe) {
         const int rcp = launch_guided_pipe(d_gray, d_t0, s, k, eps, ring_fx ? 1 : 0, d_t, handled, st);
         if (rcp != UWIE_OK || *handled) return rcp;
-    }
-    static const char *no_wave = getenv("UWIE_GF_NO_WAVE");
-    if (!no_wave) {
-        const int rcw = launch_guided_wave(d_gray, d_t0, s, k, eps, d_t, handled, st);
-        if (rcw != UWIE_OK || *handled) return rcw;
     }
     const FastGeom g8 = make_fast_geom(s, k, 8), g4 = make_fast_geom(s, k, 4), g2 = make_fast_geom(s, k, 2);
     int rc = UWIE_OK;

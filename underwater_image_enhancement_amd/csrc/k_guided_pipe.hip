@@ -1,9 +1,9 @@
 // guided_filter + clip (six_stadigy.py:26-46,178-180) as a software-pipelined wavefront kernel: the default path for the
 // reference's window widths (10, 15, 20: six_stadigy.py:234,245,255, config.py:29-53).
 //
-// Same decomposition as k_guided_wave.hip -- one autonomous wavefront owns 128 adjacent "slots" (two per lane) of a band
-// of rows and walks down one row per step, both box filters vertical-first with the horizontal window sums taken across
-// lanes through a wave-private LDS staging line, no workgroup barrier -- but the row's dependent chain
+// One autonomous wavefront owns 128 adjacent "slots" (two per lane) of a band of rows and walks down one row per step,
+// both box filters vertical-first with the horizontal window sums taken across lanes through a wave-private LDS staging
+// line, no workgroup barrier; the row's dependent chain
 //     raw rows -> vertical sums -> [LDS] -> window sums -> a, b -> ring -> vertical sums -> [LDS] -> window sums -> q
 // is cut at its two LDS round trips into three phases that run on three DIFFERENT rows in one step:
 //     step i:   C(i-2): window sums of V2 (staged by step i-1) -> q = mean_a*I + mean_b, clip -> HBM
@@ -22,8 +22,8 @@
 //             |a| <= amax and |b - b0| <= 0.45 + amax follow from 0.1 <= p <= 1 (pre-clipped transmission, S6:174) and
 //             Cauchy-Schwarz, Sa/Sb are chosen so that |fixed| < 2^30: resolution 2^-31 .. 2^-32, error of t ~ 1e-11 rms.
 //             Only offered when the transmission is pre-clipped (six_stadigy surface).
-// Guide sums (sum g, sum g*g: exact integers) and sum p, sum g*p (float64, exact: multiples of 2^-27 below 2^26) as in
-// k_guided_wave.hip; a = cov/(var+eps) from the integer forms  var*(255 K^2)^2 = K^2*sum(gg) - sum(g)^2,
+// Guide sums (sum g, sum g*g) are exact integers, sum p and sum g*p exact in float64 (multiples of 2^-27 below 2^26);
+// a = cov/(var+eps) from the integer forms  var*(255 K^2)^2 = K^2*sum(gg) - sum(g)^2,
 // cov*255*K^4 = K^2*sum(gp) - sum(g)*sum(p), one Newton step on v_rcp_f64 (2^-23 -> 2^-46).
 // Same windows and borders as cv2.boxFilter (BORDER_REFLECT_101, anchor k/2); stated tolerance on t: 1e-11 (RING_F64),
 // 5e-10 (RING_FX32) -- tests/test_gpu_stages.py.
@@ -32,7 +32,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -1042,9 +1041,7 @@ int launch_split(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCo
 {
     using C = PipeCfg<K>;
     constexpr int lds = SplitCfg<K>::lds_bytes;
-    const char *e_fold = getenv("UWIE_GF_XCD");  // (experiment knob, read per call)
-    const bool fold = !(e_fold && e_fold[0] == '0');
-    SplitGeom g{s.H, s.W, y0, band, y_end, fold ? 1 : 0};
+    SplitGeom g{s.H, s.W, y0, band, y_end, 1};  // launch order folded per XCD (measured: reads 6.50 -> 3.6 GB per launch)
     const int nstrips = cdiv(s.W, C::NV);
     {
         UWIE_PROF("k_guided_split", st);
@@ -1064,8 +1061,7 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
     const int nstrips = cdiv(s.W, C::NV);
     const int resident = 256 * std::max(1, std::min(8, (160 * 1024) / lds));
     int nbands = 1;
-    static const char *env = getenv("UWIE_GF_BANDS");
-    if (env) nbands = atoi(env);
+    if (tune().gf_bands > 0) nbands = tune().gf_bands;
     else {
         const long strips = (long)nstrips * s.B;
         if (strips < 12L * resident) nbands = (int)cdiv((size_t)(12L * resident), (size_t)strips);
@@ -1101,8 +1097,7 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
 bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
 {
     if (rows) *rows = 0;
-    const char *env_split = getenv("UWIE_GF_SPLIT");
-    if ((k != 10 && k != 15 && k != 20) || (s.W & 1) || (env_split && atoi(env_split) == 0)) return false;
+    if ((k != 10 && k != 15 && k != 20) || (s.W & 1) || !tune().gf_split) return false;
     if (s.W < 2 * k || s.H < 4 * k || s.B > 65535 || s.npx() >= ((size_t)1 << 27)) return false;
     const int RC = k, a = k / 2, Lb = k - 1 - a, NV = kPipeSlots - 2 * (k - 1);
     const bool odd = k & 1;
@@ -1110,9 +1105,9 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
     const int periods = odd ? cdiv(s.H, RC) : (s.H - 2 * a - 2 * Lb) / RC;
     if (periods < 4) return false;
     const long strips = (long)cdiv(s.W, NV) * s.B;
-    const char *env_b = getenv("UWIE_GF_BANDS");
+    const bool forced = tune().gf_bands > 0;  // (tests: the split kernel on small frames)
     int n;
-    if (env_b) n = atoi(env_b);
+    if (forced) n = tune().gf_bands;
     else {
         // ~8 wavefronts per resident slot (256 CUs x 8) even out the tail; a band costs one extra ring period
         n = (int)cdiv((size_t)(8L * 2048), (size_t)strips);
@@ -1131,7 +1126,7 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
         if (rows) *rows = periods * RC;
     }
     // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
-    return env_b || strips * n >= 1024;
+    return forced || strips * n >= 1024;
 }
 
 // ring: 0 = float64 (split ring where guided_split_plan takes the job), 1 = fixed-point int32 (requires 0.1 <= t0 <= 1:
@@ -1169,7 +1164,7 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
         cs.kb = scale;
         cs.b0 = 0.0;
     }
-    // float64: the split-ring kernel.  UWIE_GF_SPLIT=0 (read per call) keeps the general kernel.
+    // float64: the split-ring kernel.  Tuning gf_split = 0 keeps the general kernel.
     if (ring == 0) {
         int iy0, band, nb, rows;
         if (out_f32) {

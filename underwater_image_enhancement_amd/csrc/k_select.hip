@@ -389,8 +389,7 @@ constexpr int kLinStage = 512;  // candidates a block stages in LDS per group be
 uint32_t lin_cap(Shape s)
 {
     const uint32_t dflt = (uint32_t)std::max<size_t>(65536, s.npx() / 64);
-    const char *env = getenv("UWIE_LIN_CAP");
-    const long v = env ? atol(env) : 0;
+    const long v = tune().lin_cap;  // (0 outside an entry point: the workspace is sized for the default)
     return v > 0 && v < (long)dflt ? (uint32_t)v : dflt;
 }
 
@@ -904,12 +903,11 @@ int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStre
     ranks.n = 2 * nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan->ranks[j];
     uint32_t ns = 0;
-    // test knobs, read per call: UWIE_LIN_NO_PREDICT=1 switches the prediction off, UWIE_LIN_PREDICT_SHIFT=k moves the
-    // predicted windows k bins up (a large shift makes every prediction miss: collecting-sweep fallback)
-    const char *env_np = getenv("UWIE_LIN_NO_PREDICT"), *env_sh = getenv("UWIE_LIN_PREDICT_SHIFT");
-    const int shift = env_sh ? atoi(env_sh) : 0;
+    // tuning (tests): lin_no_predict switches the prediction off, lin_predict_shift = k moves the predicted windows k bins
+    // up (a large shift makes every prediction miss: collecting-sweep fallback)
+    const int shift = tune().lin_predict_shift;
     plan->predicted = false;
-    if (predict && !(env_np && atoi(env_np) == 1)) {
+    if (predict && !tune().lin_no_predict) {
         plan->predicted = true;
         // ~128 K sample pixels per frame in evenly spaced groups of four (odd stride: no column is favoured): the
         // sampling error of a 1 % rank is ~0.03 % of the frame, half a bin where the 2048 bins are equally full
@@ -942,14 +940,13 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     LinState *lin = (LinState *)plan.lin;
     UWIE_LAUNCH(k_lin_scan<float>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap);
     UWIE_LAUNCH_CHECK();
-    static const char *env_cb = getenv("UWIE_COLLECT_BLOCKS");
-    int blocks = env_cb ? atoi(env_cb) : (int)(((long long)n + 131071) / 131072);
+    int blocks = (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
     blocks = blocks < 1 ? 1 : blocks > 256 ? 256 : blocks;
     // after a prediction the sweep only serves the few planes it missed (a heavy bin next to the target made the
     // window's list overflow, or the sample was off); its blocks return at once for the others, and the ones that work
     // are alone on the chip: more, smaller blocks (4K x 64 with 4 such planes: 32 per plane 0.29 ms, 128: 0.12 ms)
-    if (plan.predicted && !env_cb) blocks = std::max(1, std::min(2 * blocks, cdiv(24576, nbc)));
+    if (plan.predicted) blocks = std::max(1, std::min(2 * blocks, cdiv(24576, nbc)));
     if (src) {
         const int per_image = std::min(3 * blocks, std::max(1, cdiv(n, 2048)));
         UWIE_LAUNCH((k_lin_collect_src<float, 4>), dim3(per_image, s.B), dim3(256), 0, st, *src, n, lin, plan.lists, plan.cap);
@@ -997,13 +994,12 @@ int select_lin_begin64(Shape s, const double *q_percent, int nq, void *ws, hipSt
     RankList ranks;
     ranks.n = 2 * nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan->ranks[j];
-    // prediction as in select_lin_begin (same test knobs)
+    // prediction as in select_lin_begin (same tuning selectors)
     uint32_t ns = 0;
-    const char *env_np = getenv("UWIE_LIN_NO_PREDICT"), *env_sh = getenv("UWIE_LIN_PREDICT_SHIFT");
-    const int shift = env_sh ? atoi(env_sh) : 0;
+    const int shift = tune().lin_predict_shift;
     plan->predicted = false;
     const int ngroups = (int)(n / 4);
-    if (predict && nq <= 2 && ngroups > 0 && !(env_np && atoi(env_np) == 1)) {
+    if (predict && nq <= 2 && ngroups > 0 && !tune().lin_no_predict) {
         plan->predicted = true;
         int stride = std::max(1, ngroups / 32768);
         if (stride > 1) stride |= 1;

@@ -86,6 +86,33 @@ class Device:
         assert img.dim() == 4 and img.shape[-1] == 3 and img.is_contiguous(), "expected contiguous [B,H,W,3]"
         return int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
 
+    # ------------------------------------------------------------------ route selectors (uwie_set_tuning)
+    def tune(self, **selectors):
+        """Set route selectors of this context (include/uwie.h: gf_pipe, gf_split, gf_bands, select_generic, restore_store,
+        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, streams, canny_prepass).  Results are the same bytes on
+        every route; tests force the fallback routes with it."""
+        for name, value in selectors.items():
+            check(self.lib.uwie_set_tuning(self._ctx, name.encode(), int(value)))
+
+    def tuning(self, **selectors):
+        """Context manager: ``with dev.tuning(lin_cap=16): ...`` sets the selectors and puts the old values back."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {}
+            for name in selectors:
+                v = ctypes.c_int()
+                check(self.lib.uwie_get_tuning(self._ctx, name.encode(), ctypes.byref(v)))
+                old[name] = v.value
+            self.tune(**selectors)
+            try:
+                yield self
+            finally:
+                self.tune(**old)
+
+        return scope()
+
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
     def profile(self, on: bool, only: str | None = None):
         """Per-kernel HIP-event timing on/off; ``only`` restricts it to one kernel name (an event pair per launch costs
