@@ -26,6 +26,10 @@
 // candidates.
 // Hysteresis is order independent (an edge pixel is a weak-or-strong pixel whose 8-connected component holds a
 // strong one), so the component formulation equals OpenCV's stack-based flood fill.
+// WEAKONLY (round 3, the edge COUNTS the quadtree wants): a strong pixel is an edge whatever it is connected to, so only the
+// WEAK candidates enter the component machinery -- components of weak pixels, "on" when some member has a strong
+// 8-neighbour -- and the count is (strong pixels) + (sizes of the on components).  On dense maps (noise inputs: nearly
+// every candidate is strong) that removes almost all labelling work; the standalone edge map keeps every candidate.
 #include "common.h"
 #include "devutil.h"
 
@@ -45,6 +49,8 @@ struct CannyBufs {
     uint32_t *nroot;   // their counts, [tile][4]
     uint32_t *nborder; // candidates on the tile's left / right column or bottom row: they lead their list, [tile][4]
     uint32_t *strong;  // [region] some pixel's gradient magnitude exceeds the high threshold (pre-pass), or nullptr
+    uint32_t *count;   // [region] edge counts, or nullptr
+    uint32_t *nstrong; // (WEAKONLY) strong pixels per tile, [tile]: k_canny_emit adds them to the counts
     int tiles;         // tiles per region in this launch
 };
 
@@ -194,21 +200,23 @@ __device__ void lds_union(uint32_t *L, int a, int b)
     }
 }
 
-template <bool PRE>
+template <bool PRE, bool WEAKONLY = false>
 __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict__ gray, const Region *__restrict__ regs,
                                                        int H, int W, int tiles_x, int low, int high, CannyBufs bufs)
 {
     __shared__ __attribute__((aligned(8))) uint8_t sg[kSG_H][kSG_W];
     __shared__ uint32_t s_lab[kCT_H * kCT_W], s_info[kCT_H * kCT_W];
-    __shared__ uint8_t s_keep[256];
+    __shared__ uint8_t s_keep[256], s_str[WEAKONLY ? 256 : 1];
     __shared__ uint32_t s_total;  // candidates in the tile
+    __shared__ uint32_t s_strong_total;  // (WEAKONLY) strong pixels in the tile
     const Region r = regs[blockIdx.y];
     const int ty0 = (blockIdx.x / tiles_x) * kCT_H, tx0 = (blockIdx.x % tiles_x) * kCT_W;  // tile origin inside the region
     const int tid = threadIdx.x;
-    if (tid == 0) s_total = 0;  // (the barrier after the tile fill orders this before the atomics)
+    if (tid == 0) s_total = s_strong_total = 0;  // (the barrier after the tile fill orders this before the atomics)
     const size_t sub = ((size_t)blockIdx.y * bufs.tiles + blockIdx.x) * 4 + (tid >> 6);  // this wavefront's list
     if (ty0 >= r.rows || tx0 >= r.cols || (!PRE && bufs.strong && !bufs.strong[blockIdx.y])) {
         if (!PRE && (tid & 63) == 0) bufs.ncand[sub] = bufs.nroot[sub] = bufs.nborder[sub] = 0;
+        if (!PRE && WEAKONLY && tid == 0) bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + blockIdx.x] = 0;
         return;
     }
     const size_t base = (size_t)r.img * H * W;
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
         return;
     }
     // non-maximum suppression, branch-free: the two neighbours along the gradient direction are selected, not branched on
-    uint32_t cls[2] = {0x01010101u, 0x01010101u}, keepmask = 0;
+    uint32_t cls[2] = {0x01010101u, 0x01010101u}, keepmask = 0, strongmask = 0;
     // a wavefront whose 8 x 64 pixels all stay at or below the low threshold (smooth water) has nothing to suppress
     int hot = 0;
 #pragma unroll
@@ -307,14 +315,22 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int n1 = isH ? mag[i + 1][j] : isV ? mag[i][j + 1] : d1;
             const int n2 = isH ? mag[i + 1][j + 2] : isV ? mag[i + 2][j + 1] : d2;
             const bool diag = !isH && !isV;
+            // (the three tests written as comparisons combined by scalar logic compiled to more selects, not fewer: 3.21 vs 3.08 ms)
             const bool keep = inside && ry0 + i < r.rows && rx0 + j < r.cols && m > low && m > n1 &&
                               (m > n2 || (!diag && m == n2));
             if (keep) {
                 keepmask |= 1u << (4 * i + j);
+                if (m > high) strongmask |= 1u << (4 * i + j);
                 cls[i] = (cls[i] & ~(0xffu << (8 * j))) | ((m > high ? 2u : 0u) << (8 * j));
             }
         }
     }
+    }
+    if constexpr (WEAKONLY) {
+        // strong pixels are edges: counted here, once per wavefront; only the weak candidates are labelled below
+        const uint32_t ns = wave_sum_u32(__popc(strongmask));
+        if (ns && (tid & 63) == 0) atomicAdd(&s_strong_total, ns);  // (ordered by the barriers below; added to the region's count at the end)
+        keepmask &= ~strongmask;
     }
     const uint32_t ncand = __popc(keepmask);
     // map bytes: one (unaligned) dword per row when the 4 pixels exist, else byte by byte
@@ -335,9 +351,29 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     // that is no union at all, where linking every pixel to its four forward neighbours took eight finds per pixel.
     if (ncand) atomicAdd(&s_total, ncand);
     s_keep[tid] = (uint8_t)keepmask;  // 4x2 candidate bits of this thread's block
+    if constexpr (WEAKONLY) s_str[tid] = (uint8_t)strongmask;
     __syncthreads();
     auto is_cand = [&](int ly, int lx) -> bool {  // tile coordinates, inside the tile
         return (s_keep[(ly >> 1) * 16 + (lx >> 2)] >> (((ly & 1) << 2) | (lx & 3))) & 1;
+    };
+    // WEAKONLY: bit b of onmask = the weak candidate b of this thread has a strong 8-neighbour inside the tile
+    uint32_t onmask = 0;
+    if constexpr (WEAKONLY) {
+        auto is_strong = [&](int ly, int lx) -> bool {
+            if ((unsigned)ly >= (unsigned)kCT_H || (unsigned)lx >= (unsigned)kCT_W) return false;
+            return (s_str[(ly >> 1) * 16 + (lx >> 2)] >> (((ly & 1) << 2) | (lx & 3))) & 1;
+        };
+        for (uint32_t km = keepmask; km; km &= km - 1) {
+            const int b = __ffs(km) - 1, ly = 2 * rp + (b >> 2), lx = 4 * cg + (b & 3);
+            const bool on = is_strong(ly - 1, lx - 1) || is_strong(ly - 1, lx) || is_strong(ly - 1, lx + 1) || is_strong(ly, lx - 1) ||
+                            is_strong(ly, lx + 1) || is_strong(ly + 1, lx - 1) || is_strong(ly + 1, lx) || is_strong(ly + 1, lx + 1);
+            if (on) onmask |= 1u << b;
+        }
+    }
+    // what a part contributes at its root: its size, and whether it is "strong" (owns a strong pixel; WEAKONLY: touches one)
+    auto part_info = [&](int b) -> uint32_t {
+        const bool st = WEAKONLY ? ((onmask >> b) & 1) != 0 : ((cls[b >> 2] >> (8 * (b & 3))) & 0xffu) == 2u;
+        return 1u | (st ? 0x10000u : 0u);
     };
     uint32_t needmask = 0, leftmask = 0;
     for (uint32_t km = keepmask; km; km &= km - 1) {
@@ -361,7 +397,12 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     // Dense tiles: size and number of strong pixels of every tile-local component are gathered at its root, and only the
     // roots are recorded for the hysteresis walk.  Sparse tiles skip that (one more barrier, an LDS atomic per
     // candidate): every candidate is recorded as a part of size one.
-    const bool dense = s_total > 256;  // block-uniform
+    const bool dense = s_total > (WEAKONLY ? 32u : 256u);  // block-uniform (weak-only lists are short: gather earlier)
+    if constexpr (WEAKONLY) {
+        // (a plain store per tile: atomics on the 4 B region counters, even one per tile, made this kernel wait on 256 hot
+        // addresses -- 4.8 ms instead of 2.6 on noise frames at 4K x 64)
+        if (tid == 0) bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + blockIdx.x] = s_strong_total;
+    }
     uint32_t myroot[8];
     {
         int k = 0;
@@ -369,10 +410,7 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
             const uint32_t root = (uint32_t)lds_find(s_lab, li);
             myroot[k] = root;
-            if (dense) {
-                const bool strong = ((cls[b >> 2] >> (8 * (b & 3))) & 0xffu) == 2u;
-                atomicAdd(&s_info[root], 1u | (strong ? 0x10000u : 0u));
-            }
+            if (dense) atomicAdd(&s_info[root], part_info(b));
         }
     }
     if (dense) __syncthreads();
@@ -389,7 +427,9 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
     // candidates that can have a neighbour in another tile (left / right column, bottom row) lead the list: the
     // cross-tile union walks only them
-    const uint32_t bordermask = keepmask & ((cg == 0 ? 0x11u : 0u) | (cg == 15 ? 0x88u : 0u) | (rp == 15 ? 0xf0u : 0u));
+    // (WEAKONLY: the top row too -- a strong neighbour in the tile above turns a weak component on)
+    const uint32_t bordermask = keepmask & ((cg == 0 ? 0x11u : 0u) | (cg == 15 ? 0x88u : 0u) | (rp == 15 ? 0xf0u : 0u) |
+                                            (WEAKONLY && rp == 0 ? 0x0fu : 0u));
     const uint32_t nb = __popc(bordermask);
     const uint32_t all3 = wave_incl_scan_u32(ncand | (nr << 10) | (nb << 20));  // one scan for the three offsets (<= 512 each)
     const uint32_t incl = all3 & 0x3ffu, rincl = (all3 >> 10) & 0x3ffu, bincl = all3 >> 20;
@@ -420,9 +460,8 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
             if (dense && (int)myroot[k] != li) continue;
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
-            const bool strong = ((cls[b >> 2] >> (8 * (b & 3))) & 0xffu) == 2u;
             bufs.flag[base + p] = 0;
-            *dst++ = make_uint2((uint32_t)p, dense ? s_info[li] : (1u | (strong ? 0x10000u : 0u)));
+            *dst++ = make_uint2((uint32_t)p, dense ? s_info[li] : part_info(b));
         }
     }
 }
@@ -491,6 +530,7 @@ __device__ __forceinline__ void for_candidates(const CannyBufs &bufs, F f)
     for_list(bufs.ncand, bufs.tiles, [&](size_t pos) { f((int)bufs.cand[pos]); });
 }
 
+template <bool WEAKONLY>
 __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     // On a dense map a tile is a handful of components and its ~200 border candidates ask for the same few unions
@@ -521,16 +561,43 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
         const int lx = (x - r.x0) % kCT_W, ly = (y - r.y0) % kCT_H;
         const bool right = x + 1 < r.x0 + r.cols, left = x - 1 >= r.x0, down = y + 1 < r.y0 + r.rows;
         const bool xr = lx == kCT_W - 1, xl = lx == 0, yd = ly == kCT_H - 1;
-        if (right && xr && cm[p + 1] != 1) link(p, p + 1);
-        if (down) {
-            if (left && (yd || xl) && cm[p + W - 1] != 1) link(p, p + W - 1);
-            if (yd && cm[p + W] != 1) link(p, p + W);
-            if (right && (yd || xr) && cm[p + W + 1] != 1) link(p, p + W + 1);
+        if constexpr (WEAKONLY) {
+            // the lists hold weak candidates only (map byte 0).  A strong neighbour (2) in another tile turns p's component
+            // on: flagged at p's tile-local root, which k_canny_mark reads; weak neighbours in another tile are linked.
+            const bool up = y - 1 >= r.y0, yu = ly == 0;
+            bool on = false;
+            if (left && xl) on = on || cm[p - 1] == 2;
+            if (right && xr) on = on || cm[p + 1] == 2;
+            if (up) {
+                if (left && (yu || xl)) on = on || cm[p - W - 1] == 2;
+                if (yu) on = on || cm[p - W] == 2;
+                if (right && (yu || xr)) on = on || cm[p - W + 1] == 2;
+            }
+            if (down) {
+                if (left && (yd || xl)) on = on || cm[p + W - 1] == 2;
+                if (yd) on = on || cm[p + W] == 2;
+                if (right && (yd || xr)) on = on || cm[p + W + 1] == 2;
+            }
+            if (on) bufs.flag[base + ld_label(L, p)] = 1;
+            if (right && xr && cm[p + 1] == 0) link(p, p + 1);
+            if (down) {
+                if (left && (yd || xl) && cm[p + W - 1] == 0) link(p, p + W - 1);
+                if (yd && cm[p + W] == 0) link(p, p + W);
+                if (right && (yd || xr) && cm[p + W + 1] == 0) link(p, p + W + 1);
+            }
+        } else {
+            if (right && xr && cm[p + 1] != 1) link(p, p + 1);
+            if (down) {
+                if (left && (yd || xl) && cm[p + W - 1] != 1) link(p, p + W - 1);
+                if (yd && cm[p + W] != 1) link(p, p + W);
+                if (right && (yd || xr) && cm[p + W + 1] != 1) link(p, p + W + 1);
+            }
         }
     });
 }
 
 // a component is an edge component iff one of its tile-local parts owns a strong pixel: flag its global root
+template <bool WEAKONLY>
 __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ regs, int H, int W, CannyBufs bufs)
 {
     const size_t base = (size_t)regs[blockIdx.y].img * H * W;
@@ -545,17 +612,27 @@ __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ r
             root = q;
         }
         if (root != p) atomicMin(L + p, root);
-        if (e.y >> 16) bufs.flag[base + root] = 1;
+        // WEAKONLY: k_canny_union flagged the tile-local roots of parts with a strong neighbour across a tile border (a flag
+        // only ever says "this pixel's component is on", whoever set it, so reading it while others write is harmless)
+        bool on = (e.y >> 16) != 0;
+        if constexpr (WEAKONLY) on = on || __hip_atomic_load(bufs.flag + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (on) bufs.flag[base + root] = 1;
     });
 }
 
 // per-region edge counts: the sizes of the tile-local parts whose global root is flagged (= hysteresis)
+template <bool WEAKONLY>
 __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ regs, int H, int W, CannyBufs bufs,
                                                     uint32_t *__restrict__ count)
 {
     const size_t base = (size_t)regs[blockIdx.y].img * H * W;
     const int32_t *L = bufs.label + base;
     uint32_t mine = 0;
+    if constexpr (WEAKONLY) {  // the strong pixels of this wavefront's tiles (for_list: 16 tiles per wavefront)
+        const int lane = threadIdx.x & 63;
+        const int tile = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kWalkTiles + lane;
+        if (lane < kWalkTiles && tile < bufs.tiles) mine = bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + tile];
+    }
     for_list(bufs.nroot, bufs.tiles, [&](size_t pos) {
         const uint2 e = bufs.roots[pos];
         int root = (int)e.x;
@@ -606,6 +683,7 @@ CannyBufs carve_canny(Carver &c, Shape s)
     b.roots = c.take<uint2>(canny_list_tiles(s) * 2048);
     b.nroot = c.take<uint32_t>(canny_list_tiles(s) * 4);
     b.nborder = c.take<uint32_t>(canny_list_tiles(s) * 4);
+    b.nstrong = c.take<uint32_t>(canny_list_tiles(s));
     b.strong = c.take<uint32_t>((size_t)s.B * 4);
     return b;
 }
@@ -639,6 +717,8 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
         return UWIE_E_INVALID;
     }
     const dim3 lgrid(cdiv(cdiv(bufs.tiles, kWalkTiles), 4), nreg);  // list walkers: 4 wavefronts per block
+    const bool weakonly = d_count && !d_edges;  // counts only: strong pixels need no labelling
+    bufs.count = d_count;
     if (d_count && !count_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
     // Pre-pass (edge counts only: the standalone edge map keeps the single pass): regions without a pixel above the high
@@ -651,18 +731,30 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
             UWIE_LAUNCH(k_canny_strong, dim3(strips * bandgroups, nreg), block, 0, st, d_gray, d_regions, s.H, s.W, strips, high,
                         bufs.strong);
         } else {
-            UWIE_LAUNCH(k_canny_gradnms<true>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+            UWIE_LAUNCH((k_canny_gradnms<true, false>), tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
         }
         UWIE_LAUNCH_CHECK();
     }
-    UWIE_LAUNCH(k_canny_gradnms<false>, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
-    UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_canny_union, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
-    UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_canny_mark, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
-    UWIE_LAUNCH_CHECK();
+    const auto k_canny_gradnms_weak = k_canny_gradnms<false, true>;  // (names as the profiler reports them)
+    const auto k_canny_gradnms_all = k_canny_gradnms<false, false>;
+    if (weakonly) {
+        UWIE_LAUNCH(k_canny_gradnms_weak, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+        UWIE_LAUNCH_CHECK();
+        UWIE_LAUNCH(k_canny_union<true>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
+        UWIE_LAUNCH_CHECK();
+        UWIE_LAUNCH(k_canny_mark<true>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
+        UWIE_LAUNCH_CHECK();
+    } else {
+        UWIE_LAUNCH(k_canny_gradnms_all, tgrid, block, 0, st, d_gray, d_regions, s.H, s.W, tiles_x, low, high, bufs);
+        UWIE_LAUNCH_CHECK();
+        UWIE_LAUNCH(k_canny_union<false>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
+        UWIE_LAUNCH_CHECK();
+        UWIE_LAUNCH(k_canny_mark<false>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs);
+        UWIE_LAUNCH_CHECK();
+    }
     if (d_count) {
-        UWIE_LAUNCH(k_canny_emit, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_count);
+        if (weakonly) UWIE_LAUNCH(k_canny_emit<true>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_count);
+        else UWIE_LAUNCH(k_canny_emit<false>, lgrid, block, 0, st, d_regions, s.H, s.W, bufs, d_count);
         UWIE_LAUNCH_CHECK();
     }
     if (d_edges) {
