@@ -52,7 +52,10 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     // from a float64 table in LDS, no range test on the divisor (t is the guided filter's output, clipped to [0.1, 1]), one
     // saturation test per group instead of four operations per value (round 3: 102 -> ~60 VALU instructions per pixel)
     constexpr bool FAST = LIN && !F64;
-    constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 && !F64 ? 256 : 128) : 1;  // 6 KB of stages (12: float64, NW 4)
+    // stages: 6 KB (12: float64, NW 4).  Measured at 4K x 64 (round 3, A/B in one run: profiles/ab.sh): 128-entry stages cost
+    // 60 % (a full stage sends its candidates to the list one global atomic each); 192-entry stages flushed twice as often
+    // with a float32 table (32.4 KB of LDS: five blocks per CU instead of four) are no faster than this
+    constexpr int NS = COLLECT ? 3 * NW : 1, SN = COLLECT ? (NW == 2 && !F64 ? 256 : 128) : 1;
     __shared__ uint32_t h[3][NB];
     __shared__ V stg[NS][SN];
     __shared__ uint32_t scount[NS], sbase[NS];
@@ -70,7 +73,8 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     V *o0 = planar + (size_t)b * 3 * npx, *o1 = o0 + npx, *o2 = o1 + npx;
     const bool aligned = (npx & 3) == 0;
     // COLLECT: the top bits of a bin's LDS counter say which window (1 .. NW) the bin belongs to, so the histogram
-    // atomic's return value tells whether the value is a candidate: no separate window test per value
+    // atomic's return value tells whether the value is a candidate: no separate window test per value (measured, round 3:
+    // atomics without a return value plus the window test in the vector unit: 1.83 instead of 1.49 ms at 4K x 64)
     constexpr int kFlagShift = NW == 2 ? 30 : 29;
     constexpr uint32_t kCntMask = (1u << kFlagShift) - 1u;
     if (COLLECT) {
