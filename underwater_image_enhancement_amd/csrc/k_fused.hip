@@ -678,15 +678,19 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     constexpr int NF = CODES ? 768 : 256;
     constexpr bool TWOSTEP = CODES || F32OUT;  // inverse gamma -> code -> final value, as two lookups
     constexpr int BASE = 1 << 14;
-    // per L (32-byte entries): {ify - 128*BASE/500, ify + 128*BASE/200 - 1, m1*y + 2^13, m4*y + 2^13 | m7*y + 2^13}: the L
-    // terms of the three matrix rows with the rounding constant, so a pixel's Y costs no instruction
-    __shared__ __attribute__((aligned(16))) int s_l[256][8];
+    // per L: the two abToXZ arguments' L parts and the L terms of the three matrix rows with the rounding constant, so a
+    // pixel's Y costs no instruction.  16-byte entries + a separate word array: entry L sits in bank quad L mod 8 (32-byte
+    // entries used four of the eight quads)
+    __shared__ __attribute__((aligned(16))) int s_l[256][4];   // {ify - 128*BASE/500, ify + 128*BASE/200 - 1, m1*y + 2^13, m4*y + 2^13}
+    __shared__ int s_l2[256];                                   // m7*y + 2^13
     __shared__ uint8_t s_invgamma[TWOSTEP ? 4096 : 1];
     __shared__ uint8_t s_fin[TWOSTEP ? 1 : 4096];  // s_fu[invgamma[.]]
     __shared__ float s_ff[NF];
     __shared__ uint8_t s_fu[NF];
     __shared__ uint32_t s_h[CODES ? 4 * 768 : 1];
-    __shared__ __attribute__((aligned(4))) uint8_t s_lut[16][256];
+    // the 4 x 4 window of tile LUTs, the four columns of a window row interleaved: word [wy][v] = {lut(wy,0)[v], .., lut(wy,3)[v]},
+    // so a pixel reads one word per window row (two, not four byte gathers) and a byte permute picks its two columns
+    __shared__ uint32_t s_lut4[4][256];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cell = blockIdx.x / nchunk, chunk = blockIdx.x - cell * nchunk;
     const int cyi = cell / (g.tx + 1), cxi = cell - cyi * (g.tx + 1);
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     {
         const int yy = T->ltoyf[2 * tid], ify = T->ltoyf[2 * tid + 1];
         *reinterpret_cast<int4 *>(&s_l[tid][0]) = make_int4(ify - 128 * BASE / 500, ify + (128 * BASE / 200 - 1), m1 * yy + (1 << 13), m4 * yy + (1 << 13));
-        s_l[tid][4] = m7 * yy + (1 << 13);
+        s_l2[tid] = m7 * yy + (1 << 13);
     }
     if (TWOSTEP)
         for (int i = tid; i < 4096; i += 256) s_invgamma[i] = T->invgamma[i];
@@ -719,11 +723,17 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         s_fu[tid] = (uint8_t)quant_u8(y);
     }
     const uint8_t *Lt = lut + (size_t)b * g.tx * g.ty * 256;
-    for (int i = tid; i < 16 * 64; i += 256) {
-        const int w = i >> 6, wy = w >> 2, wx = w & 3;
-        const int tyy = min(wy0 + wy, g.ty - 1), txx = min(wx0 + wx, g.tx - 1);
-        reinterpret_cast<uint32_t *>(&s_lut[w][0])[i & 63] =
-            reinterpret_cast<const uint32_t *>(Lt + (size_t)(tyy * g.tx + txx) * 256)[i & 63];
+    {  // thread (wy, q): values 4q .. 4q+3 of the four tile LUTs of window row wy, transposed into four words
+        const int wy = tid >> 6, q = tid & 63;
+        const int tyy = min(wy0 + wy, g.ty - 1);
+        uint32_t d[4];
+#pragma unroll
+        for (int wx = 0; wx < 4; ++wx)
+            d[wx] = reinterpret_cast<const uint32_t *>(Lt + (size_t)(tyy * g.tx + min(wx0 + wx, g.tx - 1)) * 256)[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s_lut4[wy][4 * q + k] = ((d[0] >> (8 * k)) & 255u) | (((d[1] >> (8 * k)) & 255u) << 8) | (((d[2] >> (8 * k)) & 255u) << 16) |
+                                    (((d[3] >> (8 * k)) & 255u) << 24);
     }
     __syncthreads();
     if (!TWOSTEP) {
@@ -738,7 +748,7 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
     const int gpr = (cx1 - cx0 + 3) / 4, total = (cy1 - cy0) * gpr;  // 4-pixel groups per row, in the block
     const uint32_t gmagic = (uint32_t)(((1ull << 32) + gpr - 1) / gpr);
     struct Cols {  // per 4-pixel group: LUT window columns and blend weights of its pixels (they depend on x only)
-        int c1[4], c2[4];  // byte offsets of the window columns (column * 256)
+        uint32_t sel[4];   // v_perm_b32 selector: {column c1 of row 1, c1 of row 2, c2 of row 1, c2 of row 2}
         float xa[4], xa1[4];
     };
     auto cols_of = [&](int x0) {
@@ -753,12 +763,11 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
             C.xa1[i] = 1.0f - C.xa[i];
             tx1 = max(tx1, 0);
             tx2 = min(tx2, g.tx - 1);
-            C.c1[i] = min(max(tx1 - wx0, 0), 3) * 256;
-            C.c2[i] = min(max(tx2 - wx0, 0), 3) * 256;
+            const uint32_t c1 = (uint32_t)min(max(tx1 - wx0, 0), 3), c2 = (uint32_t)min(max(tx2 - wx0, 0), 3);
+            C.sel[i] = c1 | ((4u + c1) << 8) | (c2 << 16) | ((4u + c2) << 24);  // bytes 0..3: second source, 4..7: first source
         }
         return C;
     };
-    const uint8_t *lutb = &s_lut[0][0];
     // the three LAB words of a whole group (issued one row ahead by the row-walking loop below)
     auto fetch = [&](int row, int xg, uint32_t (&w)[3]) {
         const int y = cy0 + row, x0 = cx0 + 4 * xg;
@@ -790,7 +799,7 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
         ty1 = max(ty1, 0);
         ty2 = min(ty2, g.ty - 1);
-        const uint8_t *row1 = lutb + min(max(ty1 - wy0, 0), 3) * 1024, *row2 = lutb + min(max(ty2 - wy0, 0), 3) * 1024;
+        const uint32_t *row1 = s_lut4[min(max(ty1 - wy0, 0), 3)], *row2 = s_lut4[min(max(ty2 - wy0, 0), 3)];
         const f32x2 yw = {ya1, ya};
         uint32_t o0[4], o1[4], o2[4];
         int ix[4], iz[4], yt0[4], yt1[4], yt2[4];
@@ -798,8 +807,9 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
         for (int i = 0; i < 4; ++i) {
             const int v = in4.r[i], aa = in4.g[i], bb = in4.b[i];
             // res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya, the two rows as one packed pair
-            const f32x2 l1 = {(float)row1[C.c1[i] + v], (float)row2[C.c1[i] + v]};
-            const f32x2 l2 = {(float)row1[C.c2[i] + v], (float)row2[C.c2[i] + v]};
+            const uint32_t pk = __builtin_amdgcn_perm(row2[v], row1[v], C.sel[i]);  // {l11, l21, l12, l22}
+            const f32x2 l1 = {(float)(pk & 255u), (float)((pk >> 8) & 255u)};
+            const f32x2 l2 = {(float)((pk >> 16) & 255u), (float)(pk >> 24)};
             const f32x2 rw = (l1 * C.xa1[i] + l2 * C.xa[i]) * yw;
             const float res = rw.x + rw.y;
             const int LL = min(max(__float2int_rn(res), 0), 255);
@@ -807,7 +817,7 @@ __global__ void __launch_bounds__(256) k_clahe_apply_out(const LabTables *__rest
             const int4 ly = *reinterpret_cast<const int4 *>(&s_l[LL][0]);
             yt0[i] = ly.z;
             yt1[i] = ly.w;
-            yt2[i] = s_l[LL][4];
+            yt2[i] = s_l2[LL];
             ix[i] = ly.x + (int)(((uint32_t)__umul24(aa, 5 * 53687) + (1u << 7)) >> 13);
             iz[i] = ly.y - (int)(((uint32_t)__umul24(bb, 41943) + (1u << 4)) >> 9);
         }
