@@ -377,8 +377,10 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t *ws
 // grid (tx*ty, B), block 256.  SRC 0: stored planes; 1: the restored image is recomputed from src (restore.h); 2: the
 // code-domain strategies (k_codes.hip): the u8 frame src.in goes through a per-(image, channel) code LUT (codes) and the
 // stretch is skipped.
-template <int SRC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_STRETCH_WAVES, 8))) k_stretch_lab_lut(const LabTables *__restrict__ T, const float *__restrict__ planar,
+// BS threads per block: 256, or 1024 for small jobs (one workgroup per tile is all the parallelism a single 1080p frame has:
+// 64 workgroups on 256 CUs; sixteen wavefronts walk the tile's pixels, the first four finish the histogram: 58 -> ~25 us)
+template <int SRC, int BS = 256>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS == 256 ? UWIE_STRETCH_WAVES : 4, 8))) k_stretch_lab_lut(const LabTables *__restrict__ T, const float *__restrict__ planar,
                                                          RestoreSrc src, const float *__restrict__ pct, int pct_stride,
                                                          float eps, int two, const uint8_t *__restrict__ codes, ClaheGeom g,
                                                          uint8_t *__restrict__ lab, uint8_t *__restrict__ lut)
@@ -387,16 +389,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
     __shared__ uint32_t wsum[4];
     __shared__ uint16_t s_gamma[256], s_cbrt[3072];
     __shared__ int s_fwd[9];
-    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, w4 = w;
-    for (int i = tid; i < 1024; i += 256) (&h[0][0])[i] = 0;
-    for (int i = tid; i < 256; i += 256) s_gamma[i] = T->gamma[i];
-    for (int i = tid; i < 3072; i += 256) s_cbrt[i] = T->cbrt[i];
+    const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, w = (tid >> 6) & 3, w4 = w;
+    for (int i = tid; i < 1024; i += BS) (&h[0][0])[i] = 0;
+    for (int i = tid; i < 256; i += BS) s_gamma[i] = T->gamma[i];
+    for (int i = tid; i < 3072; i += BS) s_cbrt[i] = T->cbrt[i];
     if (tid < 9) s_fwd[tid] = T->fwd[tid];
     __shared__ uint16_t s_gcode[SRC == 2 ? 768 : 1];  // gamma table after the code LUT, per channel
     Stretch S;
     if (SRC != 2) S.load(pct, b, pct_stride, eps, two);
     if (SRC == 2)
-        for (int i = tid; i < 768; i += 256) s_gcode[i] = T->gamma[codes[(size_t)b * 768 + i]];
+        for (int i = tid; i < 768; i += BS) s_gcode[i] = T->gamma[codes[(size_t)b * 768 + i]];
     __syncthreads();
     const int npx = g.H * g.W;
     const float *r0 = planar + (size_t)b * 3 * npx, *r1 = r0 + npx, *r2 = r1 + npx;
@@ -463,16 +465,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
         have_nx = n0 == 4;
         if (have_nx) R.load_four(p0, w_nx, tv_nx);
     }
-    for (int gi = tid; gi < total; gi += 256) {
+    for (int gi = tid; gi < total; gi += BS) {
         int n, p;
         group_at(gi, n, p);
         const bool have = have_nx;
         const uint32_t w[3] = {w_nx[0], w_nx[1], w_nx[2]};
         const double tv[4] = {tv_nx[0], tv_nx[1], tv_nx[2], tv_nx[3]};
         have_nx = false;
-        if (SRC == 1 && fastpath && gi + 256 < total) {
+        if (SRC == 1 && fastpath && gi + BS < total) {
             int nn, pn;
-            group_at(gi + 256, nn, pn);
+            group_at(gi + BS, nn, pn);
             have_nx = nn == 4;
             if (have_nx) R.load_four(pn, w_nx, tv_nx);
         }
@@ -569,7 +571,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
     }
     // the part of the tile that hangs over the image edge (CLAHE pads by reflection): histogram only
     if (x_lo + g.tw > g.W || y_lo + g.th > g.H) {
-        for (int i = tid; i < area; i += 256) {
+        for (int i = tid; i < area; i += BS) {
             const int ey = ty * g.th + i / g.tw, ex = txi * g.tw + i % g.tw;
             if (ey < g.H && ex < g.W) continue;
             const int p = reflect101(ey, g.H) * g.W + reflect101(ex, g.W);
@@ -599,6 +601,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UWIE_S
         pixels(R);
     }
     __syncthreads();
+    if (BS > 256 && tid >= 256) return;  // the first four wavefronts finish (ended wavefronts leave the barrier count)
     uint32_t c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
     if (g.clip > 0) {
         const uint32_t over = c > (uint32_t)g.clip ? c - g.clip : 0;
@@ -1198,7 +1201,11 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     uint8_t *lut = c.take<uint8_t>((size_t)s.B * tx * ty * 256);
     uint8_t *lab = c.take<uint8_t>((size_t)s.B * s.npx() * 3);
     const ClaheGeom g = make_geom(s, clip, tx, ty);
-    if (src)
+    const auto k_stretch_lab_lut_wide = k_stretch_lab_lut<1, 1024>;  // (name as the profiler reports it)
+    if (src && (long)tx * ty * s.B < 512 && (long)g.tw * g.th >= 8192)
+        UWIE_LAUNCH(k_stretch_lab_lut_wide, dim3(tx * ty, s.B), dim3(1024), 0, st, ctx->d_lab, d_planar, *src, d_pct, pct_stride,
+                    eps, two, (const uint8_t *)nullptr, g, lab, lut);
+    else if (src)
         UWIE_LAUNCH(k_stretch_lab_lut<1>, dim3(tx * ty, s.B), dim3(256), 0, st, ctx->d_lab, d_planar, *src, d_pct, pct_stride,
                     eps, two, (const uint8_t *)nullptr, g, lab, lut);
     else

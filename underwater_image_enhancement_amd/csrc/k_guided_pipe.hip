@@ -45,6 +45,9 @@ namespace {
         if (_rc != UWIE_OK) return _rc; \
     } while (0)
 
+#ifndef UWIE_GF_MINBAND
+#define UWIE_GF_MINBAND 32  // rows: 1080p x 1 (20 strips): 64-row bands 75 us, 32-row bands 56 us
+#endif
 constexpr int kPipeSlots = 128;
 constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: fma(x, s, kMagic) has round-to-nearest(x*s) in its low word
 
@@ -1068,7 +1071,7 @@ int launch_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeCon
         const int cap = std::max(1, s.H / (16 * (K - 1)));
         nbands = std::min(nbands, std::max(cap, (int)cdiv((size_t)(3L * resident), (size_t)strips)));
     }
-    nbands = std::max(1, std::min(nbands, s.H / std::max(64, 4 * K)));
+    nbands = std::max(1, std::min(nbands, s.H / std::max(UWIE_GF_MINBAND, 2 * K)));
     PipeGeom g{};
     g.H = s.H; g.W = s.W;
     g.band = cdiv(s.H, nbands);
