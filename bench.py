@@ -130,11 +130,16 @@ def cpu_baseline(frames_host, gpu_out_host, strategy, dist):
             "gpu_vs_oracle_bytes_compared": nbytes}
 
 
-def measured_traffic(kernel, H, W, B, strategy, launches_per_step):
-    """HBM bytes per launch of `kernel` from the committed PMC profile of this same workload (profiles/r02_traffic.json:
-    FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes), or None when the workload differs / was not profiled."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not (os.path.exists(path) and (H, W, strategy) == (2160, 3840, 2)):
+TRAFFIC_PROFILE = "profiles/r03_traffic.json"
+
+
+def measured_traffic(kernel, H, W, B, strategy, launches_per_step, dist="underwater"):
+    """HBM bytes per launch of `kernel` from the COMMITTED PMC profile of this same workload (TRAFFIC_PROFILE: FETCH_SIZE x2 +
+    WRITE_SIZE, separate rocprofv3 passes of this command, profiles/collect_r03.sh), or None when the workload differs / was
+    not profiled.  It is not measured in this run (counters need the profiler); the bench line says so in
+    roofline.traffic_source."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if not (os.path.exists(path) and (H, W, strategy, dist) == (2160, 3840, 2, "underwater")):
         return None
     table = json.load(open(path))["kernels"]
     key = kernel.replace("<TH>", "<8>").replace("<V>", "<float>")
@@ -444,7 +449,9 @@ def main():
                        "frames_per_gpu": B, "height": H, "width": W, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(name, H, W, B, args.strategy, launches_per_step), "kernel": name,
+                         "traffic": measured_traffic(name, H, W, B, args.strategy, launches_per_step, args.dist),
+                         "traffic_source": f"from committed profile {TRAFFIC_PROFILE} (rocprofv3 PMC passes of this command; not "
+                                           "measured in this run)", "kernel": name,
                          "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_launch, "rows_covered_frac": round(cover, 4),
                          "kernel_share_of_step": round(ms / args.steps / (elapsed / args.steps * 1e3), 4),

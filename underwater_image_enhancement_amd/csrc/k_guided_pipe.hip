@@ -29,6 +29,7 @@
 // 5e-10 (RING_FX32) -- tests/test_gpu_stages.py.
 #include "common.h"
 #include "devutil.h"
+#include "guided_wave.h"
 
 #include <algorithm>
 #include <cmath>
@@ -49,25 +50,11 @@ namespace {
 #define UWIE_GF_MINBAND 32  // rows: 1080p x 1 (20 strips): 64-row bands 75 us, 32-row bands 56 us
 #endif
 constexpr int kPipeSlots = 128;
-constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: fma(x, s, kMagic) has round-to-nearest(x*s) in its low word
-
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 struct PipeGeom {
     int H, W, band;
     // Border launch around an interior block that k_guided_split covers (iy1 > iy0): blockIdx.y 0 = rows [0, iy0),
     // 1 = rows [iy1, H), 2.. = the interior's own bands (iband rows each) for the strips outside [is0, is1) only.
     int iy0, iy1, iband, is0, is1;
-};
-
-struct PipeConsts {
-    double Ek;      // 255 * K^4 * eps
-    double fxa;     // 2^Sa                     (FX32)
-    double fxb;     // scale * 2^Sb             (FX32: b_fixed = lo32(fma(t3, fxb, magic_b)))
-    double magic_b; // kMagic - round(b0 * 2^Sb)
-    double kaI;     // mean_a * I = SA * kaI * g     (scale / 255 [/ 2^Sa])
-    double kb, b0;  // mean_b = SB * kb + b0
 };
 
 template <int K>
@@ -87,26 +74,6 @@ struct PipeCfg {
     static constexpr int ring_bytes(bool fx) { return RC * NLp(fx) * (fx ? 16 : 32); }
     static constexpr int lds_bytes(bool fx) { return ring_bytes(fx) + (s1_doubles + s2_doubles) * 8; }
 };
-
-__device__ __forceinline__ void pipe_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int pipe_reflect(int p, int len)
-{
-    if (p < 0) p = -p;
-    if (p > len - 1) p = 2 * (len - 1) - p;
-    return min(max(p, 0), len - 1);
-}
-
-__device__ __forceinline__ double pipe_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    return fma(fma(-x, y, 1.0), y, y);
-}
 
 // What the loads of one step return, untouched: the phases unpack at the point of use (an unpack right after the load
 // would make the wave wait for it at once -- the loads are issued a step ahead).  PAIR: a lane's two slots are adjacent
@@ -133,21 +100,6 @@ template <>
 struct RingEntry<true> {
     int32_t a[2], b[2];
 };
-
-// Raw buffer resource over one image plane (stride 0): loads take a per-lane byte offset (VGPR) plus a wave-uniform row
-// offset (SGPR), so the row loop needs no vector address arithmetic; accesses at or beyond `bytes` are dropped by the
-// hardware's range check, which is also how lanes without a valid output column skip their store (kNoStore).
-constexpr uint32_t kNoStore = 0x80000000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pipe_rsrc(const void *base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ uint32_t pipe_opaque(uint32_t v)  // keeps a loop-invariant address in its register
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
 
 template <int K, bool FX, typename TOut>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_guided_pipe(const uint8_t *__restrict__ gray, const float *__restrict__ t0,
@@ -617,9 +569,6 @@ struct RegRing<0> {
     __device__ __forceinline__ void clear() {}
 };
 
-template <int N>
-using IC = std::integral_constant<int, N>;
-
 // The last RC raw rows of a lane's two slots (transmission as float32 bits, the two guide bytes packed), in registers: the
 // row that leaves the first box filter's window is the row that entered RC steps earlier, so it is never re-read from
 // memory (those re-reads missed L2 and doubled the kernel's HBM traffic).
@@ -656,12 +605,6 @@ template <>
 struct RawRing<0> {
     template <int S> __device__ __forceinline__ void swap_at(uint32_t &, uint32_t &, uint32_t &) {}
     template <int S> __device__ __forceinline__ void set_at(uint32_t, uint32_t, uint32_t) {}
-};
-
-struct SplitGeom {
-    int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
-    int y_end;           // the last band runs to this row (shorter or longer than `band`; whole ring periods unless it is H)
-    int xcd_fold;        // fold launch order so that an XCD's workgroups are neighbours (see k_guided_split)
 };
 
 // Per window width: row buffers in flight and whether the raw rows of the window ride in registers.
@@ -1167,7 +1110,7 @@ int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k,
         cs.kb = scale;
         cs.b0 = 0.0;
     }
-    // float64: the split-ring kernel.  Tuning gf_split = 0 keeps the general kernel.
+    // float64: the split-ring kernels.  Tuning gf_split = 0 keeps the general kernel.
     if (ring == 0) {
         int iy0, band, nb, rows;
         if (out_f32) {
