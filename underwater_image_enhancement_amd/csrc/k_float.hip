@@ -41,7 +41,12 @@ __global__ void k_f_prepare(const T *__restrict__ x, const int32_t *__restrict__
 }
 
 // one lane per (image, channel): the reduction over axes (0, 1) of an HxWx3 array adds the rows of 3-vectors one after
-// the other, i.e. sequentially per channel (measured, NumPy 2.2.6)
+// the other, i.e. sequentially per channel (measured, NumPy 2.2.6).  The quotient sum / count is taken in
+// float64 and cast back: `_mean` divides the float32 sums by an np.intp count, which selects the float64 loop (checked against
+// NumPy on 2^24 + 3 pixels, where float32(count) is no longer the count: float64 division reproduces img.mean, float32 does not).
+// Contract of the float-image path: finite values (the reference documents [0, 1]); NaN handling is not reproduced (fmin /
+// fmax drop a NaN that np.min / np.clip would propagate).  The chain is one dependent addition per pixel and lane -- 8 M at
+// 4K -- which is why u8-derived images never come here (api.py routes them to the closed-form cast detection of k_entry.hip).
 template <class T>
 __global__ void k_f_mean_seq(const T *__restrict__ x, size_t npx, int B, float *__restrict__ mean_out, int32_t *__restrict__ kind)
 {
