@@ -183,3 +183,21 @@ def test_division_free_ab_to_xz_equals_the_c_expression():
         return lin if i <= 3390 else cub
 
     assert all(reference(i) == device(i) for i in range(-8145, 26869))
+
+
+def test_no_v_ashr_pk_in_the_byte_saturating_kernels(tmp_path):
+    """Round 3 compiler finding (Exactness): `saturate_cast<uchar>(x >> n)` of two adjacent values is selected as one
+    v_ashr_pk_u8_i32 on gfx950, and its result did not match on the hardware.  The kernels that saturate shifted integers to
+    bytes (RGB2LAB / LAB2RGB / CLAHE) write clamp-then-shift; this compiles them to assembly and checks that no packed
+    shift-and-saturate instruction is left (hipcc cross-compiles without a GPU)."""
+    import subprocess
+
+    src = os.path.join(ROOT, "underwater_image_enhancement_amd", "csrc")
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+             "-fno-fast-math", "-w", "-S", "--cuda-device-only"]
+    for name in ("k_fused.hip", "k_clahe.hip", "k_codes.hip"):
+        out = tmp_path / (name + ".s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(src, name), "-o", str(out)])
+        text = out.read_text()
+        assert "s_endpgm" in text
+        assert "v_ashr_pk" not in text, f"{name}: v_ashr_pk_* selected"

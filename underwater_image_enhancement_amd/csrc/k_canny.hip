@@ -397,12 +397,13 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     // Dense tiles: size and number of strong pixels of every tile-local component are gathered at its root, and only the
     // roots are recorded for the hysteresis walk.  Sparse tiles skip that (one more barrier, an LDS atomic per
     // candidate): every candidate is recorded as a part of size one.
-    const bool dense = s_total > (WEAKONLY ? 32u : 256u);  // block-uniform (weak-only lists are short: gather earlier)
-    if constexpr (WEAKONLY) {
-        // (a plain store per tile: atomics on the 4 B region counters, even one per tile, made this kernel wait on 256 hot
-        // addresses -- 4.8 ms instead of 2.6 on noise frames at 4K x 64)
-        if (tid == 0) bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + blockIdx.x] = s_strong_total;
-    }
+    // WEAKONLY always gathers (its lists are short, and a gathered component that touches no tile border is finished here)
+    const bool dense = WEAKONLY || s_total > 256u;  // block-uniform
+    // candidates that can have a neighbour in another tile (left / right column, bottom row) lead the list: the
+    // cross-tile union walks only them
+    // (WEAKONLY: the top row too -- a strong neighbour in the tile above turns a weak component on)
+    const uint32_t bordermask = keepmask & ((cg == 0 ? 0x11u : 0u) | (cg == 15 ? 0x88u : 0u) | (rp == 15 ? 0xf0u : 0u) |
+                                            (WEAKONLY && rp == 0 ? 0x0fu : 0u));
     uint32_t myroot[8];
     {
         int k = 0;
@@ -410,28 +411,48 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
             const uint32_t root = (uint32_t)lds_find(s_lab, li);
             myroot[k] = root;
-            if (dense) atomicAdd(&s_info[root], part_info(b));
+            if constexpr (WEAKONLY)  // size (12 bits: a tile has 2048 pixels) | members that touch a strong pixel | members on the tile border (< 256)
+                atomicAdd(&s_info[root], 1u | (((onmask >> b) & 1u) << 12) | (((bordermask >> b) & 1u) << 24));
+            else if (dense) atomicAdd(&s_info[root], part_info(b));
         }
     }
     if (dense) __syncthreads();
     // Lists of this (tile, wavefront), fixed slots (no atomics, nothing to wait for): every candidate, with its global
     // label starting at the root of its tile-local component, and the roots with their component's size / strength.
     // Hysteresis then only has to look at roots: a component is an edge component iff some root of it is strong.
-    uint32_t nr = 0;
+    // WEAKONLY: a component without a member on the tile border cannot grow or be switched on from outside -- it is counted
+    // here if it is on and forgotten either way: only border-touching components get a root entry, only border candidates a
+    // label and a list slot (on hazy noise most weak components are small and interior: the list walkers' work shrinks to
+    // the tile seams).
+    uint32_t rootmask = 0;
     {
+        uint32_t add = 0;
         int k = 0;
         for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
-            nr += !dense || (int)myroot[k] == li;
+            if (dense && (int)myroot[k] != li) continue;
+            if constexpr (WEAKONLY) {
+                const uint32_t info = s_info[li];
+                if ((info >> 24) == 0) {
+                    if ((info >> 12) & 0xfffu) add += info & 0xfffu;
+                    continue;
+                }
+            }
+            rootmask |= 1u << b;
+        }
+        if constexpr (WEAKONLY) {
+            const uint32_t tot = wave_sum_u32(add);
+            if (tot && (tid & 63) == 0) atomicAdd(&s_strong_total, tot);
+            __syncthreads();
+            // (a plain store per tile: atomics on the 4 B region counters, even one per tile, made this kernel wait on 256 hot
+            // addresses -- 4.8 ms instead of 2.6 on noise frames at 4K x 64)
+            if (tid == 0) bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + blockIdx.x] = s_strong_total;
         }
     }
-    // candidates that can have a neighbour in another tile (left / right column, bottom row) lead the list: the
-    // cross-tile union walks only them
-    // (WEAKONLY: the top row too -- a strong neighbour in the tile above turns a weak component on)
-    const uint32_t bordermask = keepmask & ((cg == 0 ? 0x11u : 0u) | (cg == 15 ? 0x88u : 0u) | (rp == 15 ? 0xf0u : 0u) |
-                                            (WEAKONLY && rp == 0 ? 0x0fu : 0u));
-    const uint32_t nb = __popc(bordermask);
-    const uint32_t all3 = wave_incl_scan_u32(ncand | (nr << 10) | (nb << 20));  // one scan for the three offsets (<= 512 each)
+    const uint32_t nr = __popc(rootmask);
+    const uint32_t listmask = WEAKONLY ? bordermask : keepmask;  // candidates that get a label and a list slot
+    const uint32_t nl = __popc(listmask), nb = __popc(bordermask);
+    const uint32_t all3 = wave_incl_scan_u32(nl | (nr << 10) | (nb << 20));  // one scan for the three offsets (<= 512 each)
     const uint32_t incl = all3 & 0x3ffu, rincl = (all3 >> 10) & 0x3ffu, bincl = all3 >> 20;
     const uint32_t total_b = __shfl(bincl, 63);
     if ((tid & 63) == 63) {
@@ -441,10 +462,11 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
     {
         uint32_t *dst_b = bufs.cand + sub * 512 + (bincl - nb);
-        uint32_t *dst_i = bufs.cand + sub * 512 + total_b + ((incl - bincl) - (ncand - nb));
+        uint32_t *dst_i = bufs.cand + sub * 512 + total_b + ((incl - bincl) - (nl - nb));
         int k = 0;
         for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
             const int b = __ffs(km) - 1;
+            if (!((listmask >> b) & 1)) continue;
             const int root = (int)myroot[k];
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
             const int proot = (r.y0 + ty0 + root / kCT_W) * W + r.x0 + tx0 + root % kCT_W;
@@ -455,13 +477,14 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
     if (nr) {
         uint2 *dst = bufs.roots + sub * 512 + (rincl - nr);
-        int k = 0;
-        for (uint32_t km = keepmask; km; km &= km - 1, ++k) {
+        for (uint32_t km = rootmask; km; km &= km - 1) {
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
-            if (dense && (int)myroot[k] != li) continue;
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
             bufs.flag[base + p] = 0;
-            *dst++ = make_uint2((uint32_t)p, dense ? s_info[li] : part_info(b));
+            if constexpr (WEAKONLY) bufs.label[base + p] = p;  // the root itself may be an interior pixel: the links of its border members end here
+            uint32_t info = dense ? s_info[li] : part_info(b);
+            if constexpr (WEAKONLY) info = (info & 0xfffu) | (((info >> 12) & 0xfffu) ? 0x10000u : 0u);  // {size, on}
+            *dst++ = make_uint2((uint32_t)p, info);
         }
     }
 }
@@ -617,6 +640,7 @@ __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ r
         bool on = (e.y >> 16) != 0;
         if constexpr (WEAKONLY) on = on || __hip_atomic_load(bufs.flag + base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (on) bufs.flag[base + root] = 1;
+        if (root != p) bufs.roots[pos].x = (uint32_t)root;  // k_canny_emit reads the flag there: no second walk up the links
     });
 }
 
@@ -634,11 +658,10 @@ __global__ void __launch_bounds__(256) k_canny_emit(const Region *__restrict__ r
         if (lane < kWalkTiles && tile < bufs.tiles) mine = bufs.nstrong[(size_t)blockIdx.y * bufs.tiles + tile];
     }
     for_list(bufs.nroot, bufs.tiles, [&](size_t pos) {
-        const uint2 e = bufs.roots[pos];
-        int root = (int)e.x;
-        while (L[root] != root) root = L[root];
-        if (bufs.flag[base + root]) mine += e.y & 0xffffu;
+        const uint2 e = bufs.roots[pos];  // e.x: the part's GLOBAL root (k_canny_mark wrote it back)
+        if (bufs.flag[base + e.x]) mine += e.y & 0xffffu;
     });
+    (void)L;
     const uint32_t tot = wave_sum_u32(mine);
     if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + blockIdx.y, tot);
 }
