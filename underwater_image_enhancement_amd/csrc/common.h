@@ -45,6 +45,8 @@ struct CastTables {                         // rounding tables for the sequentia
     uint32_t R[kCastBinades][256];          // RN(x_k / ulp_e)
     uint8_t tie[kCastBinades][256];         // 1 if x_k / ulp_e has fractional part exactly 1/2
     uint32_t RT[256][kCastBinades];         // R transposed, tie in bit 31 (R < 2^26): one coalesced row per value
+    uint2 RT2[128][kCastBinades];           // values 2j, 2j+1: x = low 13 bits of R as a 16-bit pair, y = R >> 13 likewise
+    uint8_t tiebin[256];                    // the one binade index in which value k ties (255: none in range)
 };
 
 void build_lab_tables(LabTables *t);

@@ -8,8 +8,8 @@
 //   * inside one binade [2^e, 2^(e+1)) of the accumulator s, fl(s + x) == s + RN_ulp(x) exactly, so a run
 //     of pixels advances s by an INTEGER number of ulps that depends only on the histogram of the run
 //     (inputs are u8/255: 256 distinct values);
-//   * k_chunk_hist writes one 3x256 histogram per 16384-pixel chunk (one streaming pass over the frame);
-//   * k_chunk_ulps turns each chunk histogram into its ulp advance for every binade of the accumulator;
+//   * k_chunk_hist takes one 3x256 histogram per 16384-pixel chunk (one streaming pass over the frame) and turns it
+//     into the chunk's ulp advance for every binade of the accumulator;
 //   * k_cast_resolve (one wavefront per image and channel) walks the chunks 64 at a time: a prefix scan over
 //     their ulp advances finds the first chunk that leaves the binade or holds a round-half-even tie, s jumps
 //     there in closed form, and that chunk is drilled: 64 lanes x 256-pixel runs, the same scan, then 64 x 4
@@ -24,113 +24,179 @@ namespace uwie {
 constexpr int kChunkPx = 16384;  // pixels per histogram chunk
 constexpr int kRunPx = 256;      // pixels per lane inside a drilled chunk (64 * 256 = kChunkPx)
 
-__global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ in, uint32_t *__restrict__ hist,
-                                                    int npx, int nchunk)
+// Per chunk, channel and binade e of the accumulator: the number of ulps the chunk advances it by,
+// D = sum_k hist[k] * RN(x_k / ulp_e), with bit 63 set when some present value ties (x_k / ulp_e = n + 1/2: the result
+// then depends on the parity of the running sum and the chunk has to be walked).
+constexpr uint64_t kTieBit = 1ull << 63;
+
+// Round 3 layout of the chunk histogram: one 32-bit word per (byte value, lane column), the three channels' counters in
+// 10-bit fields of that word.  The LDS bank of an atomic is then the lane's column (lane & 31 -- `ds_add_u32` is serviced in
+// the two 32-lane halves, banks (a/4) mod 32), never the pixel's value: no bank conflicts whatever the picture, where the
+// value-indexed copies of rounds 1-2 spent 72 % of their LDS cycles on conflicts (neighbouring pixels share their values).
+// A column receives 16384 / 32 = 512 pixels of a chunk (+1 for a ragged tail), so a field cannot overflow.
+// Output per chunk: the 768 counts as 16-bit pairs (values 2j and 2j+1 of a channel in one word: the operand layout of
+// v_dot2_u32_u16 in k_chunk_ulps), and one byte per (channel, binade) telling whether a present value ties there (a byte
+// value ties in exactly one binade, CastTables::tiebin).
+constexpr int kHistCols = 32;
+constexpr int kPairs = 3 * kCastBinades;
+static_assert(kChunkPx / kHistCols + 3 < 1024, "10-bit fields");
+static_assert(kChunkPx < 65536, "16-bit counts");
+
+__global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ in, const CastTables *__restrict__ tab,
+                                                    uint32_t *__restrict__ hist2, uint8_t *__restrict__ ties, int npx,
+                                                    int nchunk)
 {
-    // Eight copies selected by lane & 7, each 3 x 256 words + 1 of padding: neighbouring pixels mostly share their values,
-    // and equal values from different lanes of a wavefront would otherwise serialise on one LDS address (or one bank).
-    // Round 3: plain 32-bit counters (two instructions per value: shifted byte, add to the copy's base; the channel is the
-    // instruction's offset) instead of packed 16-bit ones (seven), and the next group's three words are loaded before the
-    // twelve atomics of this one: 23.6 -> ~9 VALU instructions per pixel.  The LDS atomic rate bounds the kernel (72 % of its
-    // LDS cycles are bank conflicts: neighbouring pixels share their values); a bin-major layout with sixteen word columns per
-    // bin, where the lane and not the value decides the bank, takes 49 KB (three blocks per CU) and measured 0.66 ms against
-    // 0.54 for this one (A/B in one run, profiles/ab.sh).
-    constexpr int kCopies = 8, kStride = 3 * 256 + 1;
-    __shared__ uint32_t h[kCopies * kStride];
+    __shared__ __attribute__((aligned(16))) uint32_t h[256 * kHistCols];
+    __shared__ uint32_t s_tie[kPairs];
     const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < kCopies * kStride; i += 256) h[i] = 0;
+    const uint32_t tb = tab->tiebin[tid];
+    for (int i = tid; i < 256 * kHistCols / 4; i += 256) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < kPairs) s_tie[tid] = 0;
     __syncthreads();
     const uint8_t *img = in + (size_t)b * npx * 3;
     const int p0 = c * kChunkPx, p1 = min(npx, p0 + kChunkPx);
-    uint32_t *hc = h + (tid & (kCopies - 1)) * kStride;
+    const uint32_t colb = (uint32_t)(tid & (kHistCols - 1)) * 4u;
+    char *hb = reinterpret_cast<char *>(h);
     typedef uint32_t __attribute__((aligned(1))) u32_any;
-    auto bump3 = [&](uint32_t r, uint32_t g, uint32_t bl) {
-        atomicAdd(hc + r, 1u);
-        atomicAdd(hc + 256 + g, 1u);
-        atomicAdd(hc + 512 + bl, 1u);
-    };
-    // whole groups of four pixels (12 bytes, any alignment: three dword loads), one group in flight
+    // byte address of (value, column): value * 128 + column * 4; the caller shifts the value's byte to bit 7 of the word
+    auto bump = [&](uint32_t moved, uint32_t inc) { atomicAdd(reinterpret_cast<uint32_t *>(hb + ((moved & 0x7f80u) | colb)), inc); };
+    constexpr uint32_t kR = 1u, kG = 1u << 10, kB = 1u << 20;
+    // whole groups of four pixels (12 bytes, any alignment: three dword loads); a thread's next kAhead groups are loaded
+    // (unconditionally, index clamped: no branch for the compiler to park a vmcnt(0) in) before the atomics of this batch
     const int nfull = (p1 - p0) >> 2;
-    int gidx = tid;
-    uint32_t w0 = 0, w1 = 0, w2 = 0;
-    if (gidx < nfull) {
-        const u32_any *q = reinterpret_cast<const u32_any *>(img + (size_t)(p0 + 4 * gidx) * 3);
-        w0 = q[0]; w1 = q[1]; w2 = q[2];
-    }
-    while (gidx < nfull) {
-        const uint32_t c0 = w0, c1 = w1, c2 = w2;
-        gidx += 256;
-        if (gidx < nfull) {
-            const u32_any *q = reinterpret_cast<const u32_any *>(img + (size_t)(p0 + 4 * gidx) * 3);
-            w0 = q[0]; w1 = q[1]; w2 = q[2];
+    constexpr int kAhead = 4;
+    if (nfull > 0) {
+        uint32_t cur[kAhead][3], nxt[kAhead][3];
+        auto fetch = [&](int base, uint32_t (&d)[kAhead][3]) {
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) {
+                const int g = min(base + i * 256, nfull - 1);
+                const u32_any *q = reinterpret_cast<const u32_any *>(img + (size_t)(p0 + 4 * g) * 3);
+                d[i][0] = q[0]; d[i][1] = q[1]; d[i][2] = q[2];
+            }
+        };
+        auto consume = [&](int base, const uint32_t (&d)[kAhead][3]) {
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) {
+                if (base + i * 256 < nfull) {
+                    const uint32_t c0 = d[i][0], c1 = d[i][1], c2 = d[i][2];
+                    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                    bump(c0 << 7, kR); bump(c0 >> 1, kG); bump(c0 >> 9, kB);
+                    bump(c0 >> 17, kR); bump(c1 << 7, kG); bump(c1 >> 1, kB);
+                    bump(c1 >> 9, kR); bump(c1 >> 17, kG); bump(c2 << 7, kB);
+                    bump(c2 >> 1, kR); bump(c2 >> 9, kG); bump(c2 >> 17, kB);
+                }
+            }
+        };
+        // two buffers taking turns (a register copy at the end of a trip would wait for the loads it copies)
+        constexpr int kStep = kAhead * 256;
+        fetch(tid, cur);
+        for (int base = tid; base < nfull; base += 2 * kStep) {
+            fetch(base + kStep, nxt);
+            consume(base, cur);
+            fetch(base + 2 * kStep, cur);
+            consume(base + kStep, nxt);
         }
-        // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-        bump3(c0 & 255, (c0 >> 8) & 255, (c0 >> 16) & 255);
-        bump3(c0 >> 24, c1 & 255, (c1 >> 8) & 255);
-        bump3((c1 >> 16) & 255, c1 >> 24, c2 & 255);
-        bump3((c2 >> 8) & 255, (c2 >> 16) & 255, c2 >> 24);
     }
     // the chunk's last one to three pixels (frames whose pixel count is no multiple of four)
-    for (int p = p0 + 4 * nfull + tid; p < p1; p += 256) bump3(img[(size_t)p * 3], img[(size_t)p * 3 + 1], img[(size_t)p * 3 + 2]);
+    for (int p = p0 + 4 * nfull + tid; p < p1; p += 256) {
+        bump((uint32_t)img[(size_t)p * 3] << 7, kR);
+        bump((uint32_t)img[(size_t)p * 3 + 1] << 7, kG);
+        bump((uint32_t)img[(size_t)p * 3 + 2] << 7, kB);
+    }
     __syncthreads();
-    uint32_t *out = hist + ((size_t)b * nchunk + c) * 768;
-    for (int i = tid; i < 768; i += 256) {
-        uint32_t n = 0;
+    // thread v folds the 32 columns of value v (rotated start: lane l reads bank l + k)
+    uint32_t r = 0, g = 0, bl = 0;
+#pragma unroll 8
+    for (int k = 0; k < kHistCols; ++k) {
+        const uint32_t w = h[tid * kHistCols + ((tid + k) & (kHistCols - 1))];
+        r += w & 1023u;
+        g += (w >> 10) & 1023u;
+        bl += w >> 20;
+    }
+    if (tb < (uint32_t)kCastBinades) {  // same-value stores: no atomics needed
+        if (r) s_tie[tb] = 1;
+        if (g) s_tie[kCastBinades + tb] = 1;
+        if (bl) s_tie[2 * kCastBinades + tb] = 1;
+    }
+    const uint32_t r2 = r | (__shfl_down(r, 1) << 16), g2 = g | (__shfl_down(g, 1) << 16), b2 = bl | (__shfl_down(bl, 1) << 16);
+    const size_t chunk = (size_t)b * nchunk + c;
+    if (!(tid & 1)) {
+        uint32_t *out = hist2 + chunk * 384 + (tid >> 1);
+        out[0] = r2; out[128] = g2; out[256] = b2;
+    }
+    __syncthreads();
+    if (tid < kPairs) ties[chunk * kPairs + tid] = (uint8_t)s_tie[tid];
+}
+
+// D for kUlpChunks chunks x 3 channels (48 rows) per block.  D = sum_k n_k R_k with n_k <= 16384 summing to at most 16384
+// and R_k < 2^26: R = hi * 2^13 + lo, both sums stay below 2^27, and v_dot2_u32_u16 takes two values per instruction from
+// the pair tables (CastTables::RT2) -- one instruction per (row, value, binade) where the 64-bit mad + tie count of rounds
+// 1-2 took three, with the table staged in LDS once per 16 chunks instead of fetched from L2 inside the loop.
+// A thread owns one binade and eight rows; only the binades a frame of `npx` pixels can reach are computed (nb).
+constexpr int kUlpChunks = 16, kUlpRows = 3 * kUlpChunks, kUlpRowStride = kUlpRows + 4, kUlpGroups = kUlpRows / 8;
+static_assert(kUlpGroups * kCastBinades <= 256, "one thread per (binade, row group)");
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256) k_chunk_ulps(const uint32_t *__restrict__ hist2, const uint8_t *__restrict__ ties,
+                                                    const CastTables *__restrict__ tab, int total_chunks, int nb,
+                                                    uint64_t *__restrict__ ulps)
+{
+    __shared__ uint2 t2[128 * kCastBinades];
+    __shared__ __attribute__((aligned(16))) uint32_t n2[128 * kUlpRowStride];
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * kUlpChunks, nc = min(kUlpChunks, total_chunks - g0);
+    {
+        const uint2 *src = &tab->RT2[0][0];
+        static_assert(128 * kCastBinades % 256 == 0, "whole trips");
+        // fully unrolled: all loads of a thread in flight together (a rolled loop pays one L2 round trip per element)
 #pragma unroll
-        for (int k = 0; k < kCopies; ++k) n += h[k * kStride + i];
-        out[i] = n;
+        for (int i = 0; i < 128 * kCastBinades / 256; ++i) t2[tid + 256 * i] = src[tid + 256 * i];
+        const int kp = tid & 127, r0 = (tid >> 7) * (kUlpRows / 2);
+        uint32_t w[kUlpRows / 2];
+#pragma unroll
+        for (int i = 0; i < kUlpRows / 2; ++i) {
+            // row = 3 * chunk + channel: consecutive rows are consecutive 128-word runs of hist2.  Clamped, not predicated: a
+            // load under a branch gets its own vmcnt(0), 24 round trips instead of one.
+            const int row = min(r0 + i, 3 * nc - 1);
+            w[i] = hist2[((size_t)g0 * 3 + row) * 128 + kp];
+        }
+#pragma unroll
+        for (int i = 0; i < kUlpRows / 2; ++i) n2[kp * kUlpRowStride + r0 + i] = r0 + i < 3 * nc ? w[i] : 0u;
+    }
+    __syncthreads();
+    const int rg = tid / kCastBinades, ei = tid - rg * kCastBinades;
+    if (rg >= kUlpGroups || ei >= nb) return;
+    uint32_t lo[8] = {}, hi[8] = {};
+    uint8_t tz[8];  // fetched ahead of the loop, clamped rows (see above)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tz[q] = ties[((size_t)g0 * 3 + min(rg * 8 + q, 3 * nc - 1)) * kCastBinades + ei];
+#pragma unroll 4
+    for (int kp = 0; kp < 128; ++kp) {
+        const uint2 t = t2[kp * kCastBinades + ei];
+        const uint4 na = *reinterpret_cast<const uint4 *>(&n2[kp * kUlpRowStride + rg * 8]);
+        const uint4 nb4 = *reinterpret_cast<const uint4 *>(&n2[kp * kUlpRowStride + rg * 8 + 4]);
+        const uint32_t n[8] = {na.x, na.y, na.z, na.w, nb4.x, nb4.y, nb4.z, nb4.w};
+        const u16x2_t tl = __builtin_bit_cast(u16x2_t, t.x), th = __builtin_bit_cast(u16x2_t, t.y);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const u16x2_t nq = __builtin_bit_cast(u16x2_t, n[q]);
+            lo[q] = __builtin_amdgcn_udot2(nq, tl, lo[q], false);
+            hi[q] = __builtin_amdgcn_udot2(nq, th, hi[q], false);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = rg * 8 + q;
+        if (row >= 3 * nc) break;
+        const size_t o = ((size_t)g0 * 3 + row) * kCastBinades + ei;
+        ulps[o] = (((uint64_t)hi[q] << 13) + lo[q]) | (tz[q] ? kTieBit : 0);
     }
 }
 
 __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
 {
     return __uint_as_float(((uint32_t)(e + 127) << 23) | (S & 0x7fffffu));
-}
-
-// Per chunk, channel and binade e of the accumulator: the number of ulps the chunk advances it by,
-// D = sum_k hist[k] * RN(x_k / ulp_e), with bit 63 set when some present value ties (x_k / ulp_e = n + 1/2: the result
-// then depends on the parity of the running sum and the chunk has to be walked).  One thread per (channel, binade).
-constexpr uint64_t kTieBit = 1ull << 63;
-
-constexpr int kUlpChunks = 4;  // chunks per block: a table entry is fetched once for all of them
-
-__global__ void __launch_bounds__(128) k_chunk_ulps(const uint32_t *__restrict__ hist, const CastTables *__restrict__ tab,
-                                                    int nchunk, uint64_t *__restrict__ ulps)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t h[kUlpChunks][768];
-    const int c0 = blockIdx.x * kUlpChunks, nc = min(kUlpChunks, nchunk - c0);
-    const size_t chunk0 = (size_t)blockIdx.y * nchunk + c0;
-    for (int i = threadIdx.x; i < kUlpChunks * 768; i += 128) {
-        const int j = i / 768;
-        (&h[0][0])[i] = j < nc ? hist[chunk0 * 768 + i] : 0u;
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= 3 * kCastBinades) return;
-    const int ch = t / kCastBinades, ei = t - ch * kCastBinades;
-    uint64_t D[kUlpChunks] = {};
-    uint32_t tie[kUlpChunks] = {};  // number of pixels whose value ties in this binade (only its being zero matters)
-#pragma unroll 2
-    for (int k = 0; k < 256; k += 4) {
-        uint32_t rv[4], tb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t rt = tab->RT[k + q][ei];  // threads of one channel read one 136-byte row
-            rv[q] = rt & 0x7fffffffu;
-            tb[q] = rt >> 31;
-        }
-#pragma unroll
-        for (int j = 0; j < kUlpChunks; ++j) {
-            const uint4 n4 = *reinterpret_cast<const uint4 *>(&h[j][ch * 256 + k]);
-            const uint32_t n[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                D[j] += (uint64_t)n[q] * rv[q];
-                tie[j] = __umul24(n[q], tb[q]) + tie[j];  // n <= 16384
-            }
-        }
-    }
-    for (int j = 0; j < nc; ++j) ulps[((chunk0 + j) * 3 + ch) * kCastBinades + ei] = D[j] | (tie[j] ? kTieBit : 0);
 }
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
@@ -233,7 +299,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
                 if (L >= kWave) break;
                 const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));  // wavefront-uniform
                 if constexpr (per > 4) {
-                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
+                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row, cached, px_after + (p0 + cnt - q0 - qn));
                 } else {
                     s = add_in_order(chan, q0, qn, s, lane);
                 }
@@ -252,7 +318,7 @@ __device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float 
         if (L >= kWave) break;
         const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));
         if constexpr (per > 4) {
-            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row + 256, cached + 1, px_after + (p0 + cnt - q0 - qn));
+            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row, cached, px_after + (p0 + cnt - q0 - qn));
         } else {
             s = add_in_order(chan, q0, qn, s, lane);
         }
@@ -268,13 +334,14 @@ __global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__
                                                      const CastTables *__restrict__ tab, int npx, int nchunk,
                                                      float *__restrict__ sums)
 {
-    __shared__ ulonglong2 row[2][256];  // table rows of the two binades in play, one set per drill level
+    __shared__ ulonglong2 row[1][256];  // table rows of the two binades in play; the drill levels share them (a level looks
+                                        // its rows up once per pass, before it descends)
     const int ch = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const uint8_t *chan = in + (size_t)b * npx * 3 + ch;
     const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
     float s = 0.0f;
     int c = 0;
-    int cached[3] = {-1, -1, -1};  // binade whose table rows each drill level's LDS buffer holds
+    int cached[1] = {-1};  // binade whose table rows the LDS buffer holds
     while (c < nchunk) {
         int L = 0;  // chunks passed in closed form
         if (s >= 0.25f) {
@@ -325,7 +392,8 @@ size_t cast_ws_bytes(Shape s)
 {
     Carver c(nullptr);
     const int nchunk = cdiv((long long)s.npx(), kChunkPx);
-    c.take<uint32_t>((size_t)s.B * nchunk * 768);
+    c.take<uint32_t>((size_t)s.B * nchunk * 384);
+    c.take<uint8_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     c.take<uint64_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     c.take<float>((size_t)s.B * 3);
     return c.total();
@@ -337,12 +405,16 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     Carver c(ws);
     const int npx = (int)s.npx();
     const int nchunk = cdiv(npx, kChunkPx);
-    uint32_t *hist = c.take<uint32_t>((size_t)s.B * nchunk * 768);
+    uint32_t *hist2 = c.take<uint32_t>((size_t)s.B * nchunk * 384);
+    uint8_t *ties = c.take<uint8_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     uint64_t *ulps = c.take<uint64_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     float *sums = c.take<float>((size_t)s.B * 3);
-    UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, hist, npx, nchunk);
+    UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, ctx->d_cast, hist2, ties, npx, nchunk);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_chunk_ulps, dim3(cdiv(nchunk, kUlpChunks), s.B), dim3(128), 0, st, hist, ctx->d_cast, nchunk, ulps);
+    // the accumulator never exceeds the pixel count: binades above floor(log2(npx)) are never asked for
+    const int nb = std::min(kCastBinades, (31 - __builtin_clz((unsigned)std::max(npx, 1))) - kCastBinadeMin + 1);
+    UWIE_LAUNCH(k_chunk_ulps, dim3(cdiv(s.B * nchunk, kUlpChunks)), dim3(256), 0, st, hist2, ties, ctx->d_cast, s.B * nchunk, nb,
+                ulps);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, ulps, ctx->d_cast, npx, nchunk, sums);
     UWIE_LAUNCH_CHECK();

@@ -127,6 +127,17 @@ void build_cast_tables(CastTables *t)
             t->RT[k][ei] = (uint32_t)R | (tie ? 0x80000000u : 0u);
         }
     }
+    for (int k = 0; k < 256; ++k) {
+        t->tiebin[k] = 255;
+        for (int ei = 0; ei < kCastBinades; ++ei) {
+            const uint32_t R = t->R[ei][k];
+            uint32_t &lo = t->RT2[k >> 1][ei].x, &hi = t->RT2[k >> 1][ei].y;
+            if (!(k & 1)) lo = hi = 0;
+            lo |= (R & 0x1fffu) << (16 * (k & 1));
+            hi |= (R >> 13) << (16 * (k & 1));  // R < 2^26
+            if (t->tie[ei][k]) t->tiebin[k] = (uint8_t)ei;  // x / ulp = n + 1/2 pins the ulp: at most one binade
+        }
+    }
 }
 
 }  // namespace uwie
