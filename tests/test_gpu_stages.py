@@ -65,6 +65,10 @@ def test_cast_classify_matches_numpy_sequential_mean(dev, orc, frames, golden):
     cases["bright_1080p"] = rng.integers(180, 256, (1080, 1920, 3), dtype=np.uint8)
     cases["sparse_300x400"] = ((rng.random((300, 400, 3)) < 0.002) * rng.integers(0, 256, (300, 400, 3))).astype(np.uint8)
     cases["zeros_64x64"] = np.zeros((64, 64, 3), np.uint8)
+    cases["white_257x129"] = np.full((257, 129, 3), 255, np.uint8)  # (a ragged last chunk, every add of one size)
+    cases["odd_1031x517"] = rng.integers(0, 256, (1031, 517, 3), dtype=np.uint8)
+    cases["dark_4k"] = (rng.random((2160, 3840, 3)) < 0.3).astype(np.uint8) * rng.integers(0, 4, (2160, 3840, 3), dtype=np.uint8)
+    cases["steps_2k"] = np.repeat(np.arange(0, 256, dtype=np.uint8), 3 * 2048 * 4).reshape(2048, 1024, 3)  # long constant runs
     for tag in GOLDEN_TAGS:
         cases["golden_" + tag] = golden[f"{tag}/u8"]
     for name, u8 in cases.items():

@@ -108,6 +108,7 @@ struct uwie_ctx {
     int device;
     uwie::Tuning tune;
     bool attr_q_tail = false;   // > 64 KB LDS attributes set on this context's device: k_q_tail,
+    bool attr_cast_resolve = false;  // k_cast_resolve (the rounding table of every binade: 70 KB),
     int attr_gf_fast = 0;       // k_guided_fast<TH> (bit TH)
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;

@@ -201,170 +201,206 @@ __device__ __forceinline__ float from_mantissa(uint32_t S, int e)
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 
-// s + x[q0] + x[q0+1] + ... (qn <= 4 pixels, one after the other like NumPy): the lanes fetch the pixels side by side (one
-// memory round trip instead of qn), every lane then adds them in order.
-__device__ __forceinline__ float add_in_order(const uint8_t *__restrict__ chan, int q0, int qn, float s, int lane)
-{
-    const float x = lane < qn ? px_norm_fast(chan[(size_t)(q0 + lane) * 3]) : 0.0f;
-    for (int i = 0; i < qn; ++i) s = s + __shfl(x, i);
-    return s;
-}
+// ---- k_cast_resolve: one block of 16 wavefronts per (image, channel).
+// Wavefront 0 walks the chunks 64 at a time: lane j holds the ulp count of chunk c+j for the current binade, a prefix scan
+// finds the first chunk that leaves the binade or ties, s jumps to that chunk in closed form.  The whole block then drills
+// that chunk: 1024 threads x 16 pixels, every thread sums the table entries of its pixels for binades e and e+1 (the table
+// of all binades sits in LDS), a two-level prefix scan finds the first thread whose pixels leave the binade or tie, s jumps
+// there in closed form, that thread's 16 pixels are added one by one like NumPy does, and the scan resumes behind it.  A
+// binade is left ~24 times per channel at 4K.  (Rounds 1-2: one wavefront per channel drilling 64 x 256 pixels, then 64 x 4,
+// with the two table rows in play fetched from global memory at every level and binade change: 142 us of a 1080p frame's
+// 800; the 16384 table look-ups of a drill are LDS-rate bound and a single wavefront gets a fifth of that rate.)
+constexpr int kResolveThreads = 1024, kResolveWaves = kResolveThreads / kWave, kResolvePer = kChunkPx / kResolveThreads;
+constexpr int kTblCols = kCastBinades + 1;  // entry [v][e+1] exists for every binade (the last column repeats)
+static_assert(kResolvePer == 16, "four packed dwords of pixels per thread");
 
-// Advance the accumulator `s` over pixels [p0, p0+cnt) of one channel (stride 3 bytes); all 64 lanes call.
-// Lanes take `per` consecutive pixels each.  One pass over the pixels gives every lane its ulp advance for the current
-// binade e AND for e+1 (the table rows of both sit in LDS), so the pixels are read once per call: a prefix scan finds the
-// first lane whose pixels leave the binade or tie, s jumps there in closed form, that lane's pixels are split 64 ways
-// again (per -> per/64, last level: 4 pixels added one by one), and the scan resumes behind it with the row of the binade
-// s is in by then.
-template <int per>
-__device__ float drill(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const CastTables *tab, ulonglong2 *row, int *cached,
-                       long long px_after)
+struct ResolveShared {
+    uint64_t wtot[kResolveWaves];   // ulp advance of each wavefront's threads
+    uint64_t wadv[kResolveWaves];   // advance in front of the wavefront's first bad thread
+    uint32_t wbad[kResolveWaves];   // that thread's lane (64: none)
+    uint32_t px[kResolveWaves][4];  // its sixteen pixels
+    float s;
+    int c;
+};
+
+// Advance the accumulator `s` over pixels [p0, p0+cnt) of one channel (stride 3 bytes); all threads of the block call with
+// the same arguments and return the same value.
+__device__ float drill_block(const uint8_t *__restrict__ chan, int p0, int cnt, float s, const uint64_t *__restrict__ tbl,
+                             ResolveShared &sh, bool more_after)
 {
-    // px_after: pixels of the buffer that follow pixel p0 + cnt - 1 (reads may run 2 bytes past a lane's last pixel)
-    const int lane = threadIdx.x & 63;
-    const int ln = max(0, min(per, cnt - lane * per));
-    const long long ahead = px_after + max(0, cnt - (lane + 1) * per);  // ... that follow this lane's run
-    const uint8_t *run = chan + (size_t)(p0 + lane * per) * 3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // this thread's sixteen pixels, one byte each (missing pixels: 0, which adds nothing anywhere below)
+    uint32_t vals[4] = {0, 0, 0, 0};
+    {
+        const int ln = max(0, min(kResolvePer, cnt - t * kResolvePer));
+        const uint8_t *run = chan + (size_t)(p0 + t * kResolvePer) * 3;
+        // 48 bytes = 12 (unaligned) dwords; the last one reaches two bytes past the sixteenth pixel's byte
+        if (ln == kResolvePer && (more_after || t * kResolvePer + kResolvePer < cnt)) {
+            const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(run);
+            uint32_t d[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) d[q] = w[q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int byte = 3 * q;
+                vals[q >> 2] |= ((d[byte >> 2] >> (8 * (byte & 3))) & 0xffu) << (8 * (q & 3));
+            }
+        } else {
+            for (int q = 0; q < ln; ++q) vals[q >> 2] |= (uint32_t)run[(size_t)q * 3] << (8 * (q & 3));
+        }
+    }
+    auto first_bad = [&](bool bad, uint64_t adv_here, uint64_t &adv) {  // -> global index of the first thread with `bad`
+        const uint64_t mask = __ballot(bad);
+        const int Lw = mask ? (int)__builtin_ctzll(mask) : kWave;
+        const uint64_t a = shfl_u64(adv_here, min(Lw, kWave - 1));
+        if (lane == Lw) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sh.px[wave][q] = vals[q];
+        }
+        if (lane == 0) {
+            sh.wbad[wave] = (uint32_t)Lw;
+            sh.wadv[wave] = a;
+        }
+        __syncthreads();
+        int L = kResolveThreads;
+        adv = 0;
+#pragma unroll
+        for (int j = kResolveWaves - 1; j >= 0; --j) {
+            const uint32_t lw = sh.wbad[j];
+            if (lw < (uint32_t)kWave) {
+                L = j * kWave + (int)lw;
+                adv = sh.wadv[j];
+            }
+        }
+        return L;
+    };
+    auto add_thread = [&](int L, float acc) {  // the sixteen pixels of thread L, one after the other like NumPy
+        const uint32_t *q = sh.px[L >> 6];
+        const uint32_t w[4] = {q[0], q[1], q[2], q[3]};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = acc + px_norm_fast((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        return acc;
+    };
     int first = 0;
-    while (first < kWave) {
-        int L;  // the lane whose pixels have to be looked at more closely
+    while (first < kResolveThreads) {
+        int L;
         if (s >= 0.25f) {
             const int e = (int)(__float_as_uint(s) >> 23) - 127;
-            const int ei = min(e - kCastBinadeMin, kCastBinades - 1), ei1 = min(ei + 1, kCastBinades - 1);
-            // the rows of binades e and e+1 stay in this level's LDS buffer until the accumulator leaves e (a binade is
-            // left ~24 times per channel, a drill happens for every tie as well: one global round trip less per drill)
-            if (*cached != ei) {
-                __builtin_amdgcn_wave_barrier();
-                // one 16-byte entry per byte value: the ulp count of binade e (and e+1) with its tie flag moved up to bit 40, so
-                // that one 64-bit add per binade and pixel accumulates both (256 counts below 2^26 stay below 2^34)
-                for (int k = lane; k < 256; k += 64) {
-                    const uint32_t r0 = tab->RT[k][ei], r1 = tab->RT[k][ei1];
-                    row[k] = make_ulonglong2((uint64_t)(r0 & 0x7fffffffu) | ((uint64_t)(r0 >> 31) << 40),
-                                             (uint64_t)(r1 & 0x7fffffffu) | ((uint64_t)(r1 >> 31) << 40));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                *cached = ei;
-            }
+            const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
+            // one 64-bit entry per (byte value, binade): the ulp count with its tie flag moved up to bit 40, so that one 64-bit
+            // add per binade and pixel accumulates both (16 counts below 2^26 stay far below 2^40)
             uint64_t D[2] = {0, 0};
-            uint32_t T[2] = {0, 0};
-            auto add = [&](uint32_t u) {
-                const ulonglong2 v = row[u];
-                D[0] += v.x;
-                D[1] += v.y;
-            };
-            if (lane >= first) {
-                int i = 0;
-                if constexpr (per >= 64) {
-                    // 16 pixels = 48 bytes = 12 (unaligned) dwords; STEPS such groups per trip with all their loads in flight
-                    // together (the lookups below wait for memory once per trip: a run of 256 pixels is 4 trips, not 16).
-                    // The 12th dword of a group reaches up to 2 bytes past its last pixel: `ahead` pixels of the buffer
-                    // follow this lane's run, so only the buffer's very last group is left to the byte loop.
-                    auto steps = [&](auto n_c) {
-                        constexpr int STEPS = decltype(n_c)::value;
-                        for (; i + 16 * STEPS <= ln && (i + 16 * STEPS < ln || ahead > 0); i += 16 * STEPS) {
-                            const u32_unaligned *w = reinterpret_cast<const u32_unaligned *>(run + (size_t)i * 3);
-                            uint32_t d[12 * STEPS];
+            if (t >= first) {
+                const uint64_t *te = tbl + ei;
 #pragma unroll
-                            for (int q = 0; q < 12 * STEPS; ++q) d[q] = w[q];
-#pragma unroll
-                            for (int q = 0; q < 16 * STEPS; ++q) {
-                                const int byte = 3 * q;
-                                add((d[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
-                            }
-                        }
-                    };
-                    steps(std::integral_constant<int, 16>{});
-                    steps(std::integral_constant<int, 4>{});
-                    steps(std::integral_constant<int, 1>{});
+                for (int i = 0; i < 16; ++i) {
+                    const uint64_t *q = te + ((vals[i >> 2] >> (8 * (i & 3))) & 0xffu) * kTblCols;
+                    D[0] += q[0];
+                    D[1] += q[1];
                 }
-                for (; i < ln; ++i) add(run[(size_t)i * 3]);
             }
-            // the tie counts rode above bit 40
-            T[0] = (uint32_t)(D[0] >> 40); T[1] = (uint32_t)(D[1] >> 40);
-            D[0] &= (1ull << 40) - 1; D[1] &= (1ull << 40) - 1;
-            // events inside this pass: as long as s stays in e or e+1 the lane sums above remain valid
+            const uint32_t T[2] = {(uint32_t)(D[0] >> 40), (uint32_t)(D[1] >> 40)};
+            D[0] &= (1ull << 40) - 1;
+            D[1] &= (1ull << 40) - 1;
+            // events inside this pass: as long as s stays in e or e+1 the sums above remain valid
             for (;;) {
                 const int ec = (int)(__float_as_uint(s) >> 23) - 127;
-                if (ec != e && !(ec == e + 1 && ei1 == ei + 1)) { L = -1; break; }  // another binade: new pass
+                if (ec != e && !(ec == e + 1 && ei + 1 < kCastBinades)) { L = -1; break; }  // another binade: new pass
                 const int w = ec - e;
-                const uint64_t incl = wave_incl_scan_u64(lane >= first ? D[w] : 0);
-                const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
-                const bool bad = lane >= first && (T[w] != 0 || S + incl >= (1ull << 24));
-                const uint64_t mask = __ballot(bad);
-                L = mask ? (int)__builtin_ctzll(mask) : kWave;
-                const uint64_t adv = L > first ? shfl_u64(incl, L - 1) : 0;
-                s = from_mantissa(S + (uint32_t)adv, ec);
-                if (L >= kWave) break;
-                const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));  // wavefront-uniform
-                if constexpr (per > 4) {
-                    s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row, cached, px_after + (p0 + cnt - q0 - qn));
-                } else {
-                    s = add_in_order(chan, q0, qn, s, lane);
+                const uint64_t incl = wave_incl_scan_u64(t >= first ? D[w] : 0);
+                if (lane == kWave - 1) sh.wtot[wave] = incl;
+                __syncthreads();
+                uint64_t offs = 0, total = 0;
+#pragma unroll
+                for (int j = 0; j < kResolveWaves; ++j) {
+                    const uint64_t v = sh.wtot[j];
+                    offs += j < wave ? v : 0;
+                    total += v;
                 }
+                const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
+                const bool bad = t >= first && (T[w] != 0 || S + offs + incl >= (1ull << 24));
+                uint64_t adv;
+                L = first_bad(bad, offs + incl - (t >= first ? D[w] : 0), adv);  // (exclusive prefix of the bad thread)
+                if (L >= kResolveThreads) adv = total;
+                s = from_mantissa(S + (uint32_t)adv, ec);
+                if (L >= kResolveThreads) break;
+                s = add_thread(L, s);
                 first = L + 1;
-                if (first >= kWave) break;
+                if (first >= kResolveThreads) break;
             }
             if (L < 0) continue;
-            break;  // L >= kWave or every lane consumed
+            break;  // no bad thread left, or every thread consumed
         }
-        // tiny accumulator: skip lanes whose pixels are all zero (adding 0.0f changes nothing)
-        bool nz = false;
-        if (lane >= first)
-            for (int i = 0; i < ln; ++i) nz |= run[(size_t)i * 3] != 0;
-        const uint64_t mask = __ballot(nz);
-        L = mask ? (int)__builtin_ctzll(mask) : kWave;
-        if (L >= kWave) break;
-        const int q0 = p0 + L * per, qn = max(0, min(per, cnt - L * per));
-        if constexpr (per > 4) {
-            s = drill<(per >= 64 * 4 ? per / 64 : 4)>(chan, q0, qn, s, tab, row, cached, px_after + (p0 + cnt - q0 - qn));
-        } else {
-            s = add_in_order(chan, q0, qn, s, lane);
-        }
+        // tiny accumulator: skip threads whose pixels are all zero (adding 0.0f changes nothing)
+        uint64_t unused;
+        L = first_bad(t >= first && (vals[0] | vals[1] | vals[2] | vals[3]) != 0, 0, unused);
+        if (L >= kResolveThreads) break;
+        s = add_thread(L, s);
         first = L + 1;
+        __syncthreads();  // (sh.px / sh.wbad are written again before the next barrier on this path)
     }
+    __syncthreads();
     return s;
 }
 
-// One wavefront per (image, channel): 64 chunks per step.  Lane j holds the ulp count of chunk c+j for the current
-// binade; a prefix scan finds the first chunk that leaves the binade or ties, s jumps to that chunk in closed form,
-// the chunk is drilled, and the walk resumes behind it (a binade is left ~24 times per channel at 4K).
-__global__ void __launch_bounds__(64) k_cast_resolve(const uint8_t *__restrict__ in, const uint64_t *__restrict__ ulps,
-                                                     const CastTables *__restrict__ tab, int npx, int nchunk,
-                                                     float *__restrict__ sums)
+__global__ void __launch_bounds__(kResolveThreads) k_cast_resolve(const uint8_t *__restrict__ in, const uint64_t *__restrict__ ulps,
+                                                                  const CastTables *__restrict__ tab, int npx, int nchunk,
+                                                                  float *__restrict__ sums)
 {
-    __shared__ ulonglong2 row[1][256];  // table rows of the two binades in play; the drill levels share them (a level looks
-                                        // its rows up once per pass, before it descends)
-    const int ch = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    extern __shared__ uint64_t tbl[];  // [256][kTblCols]
+    __shared__ ResolveShared sh;
+    const int ch = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    {
+        constexpr int kTrips = (256 * kTblCols + kResolveThreads - 1) / kResolveThreads;
+        uint32_t r[kTrips];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {  // (clamped, all in flight)
+            const int i = min(t + k * kResolveThreads, 256 * kTblCols - 1);
+            r[k] = tab->RT[i / kTblCols][min(i % kTblCols, kCastBinades - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int i = t + k * kResolveThreads;
+            if (i < 256 * kTblCols) tbl[i] = (uint64_t)(r[k] & 0x7fffffffu) | ((uint64_t)(r[k] >> 31) << 40);
+        }
+    }
+    __syncthreads();
     const uint8_t *chan = in + (size_t)b * npx * 3 + ch;
     const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
     float s = 0.0f;
     int c = 0;
-    int cached[1] = {-1};  // binade whose table rows the LDS buffer holds
-    while (c < nchunk) {
-        int L = 0;  // chunks passed in closed form
-        if (s >= 0.25f) {
-            const int e = (int)(__float_as_uint(s) >> 23) - 127;
-            const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
-            const bool have = c + lane < nchunk;
-            const uint64_t v = have ? u[(size_t)(c + lane) * 3 * kCastBinades + ei] : kTieBit;
-            const uint64_t incl = wave_incl_scan_u64(v & ~kTieBit);
-            const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
-            const bool bad = (v & kTieBit) || S + incl >= (1ull << 24);
-            const uint64_t mask = __ballot(bad);
-            L = mask ? (int)__builtin_ctzll(mask) : kWave;
-            const uint64_t adv = L > 0 ? shfl_u64(incl, L - 1) : 0;
-            s = from_mantissa(S + (uint32_t)adv, e);
-            c += L;
-            if (L == kWave || c >= nchunk) continue;
+    for (;;) {
+        if (t < kWave) {  // chunks passed in closed form
+            while (c < nchunk && s >= 0.25f) {
+                const int e = (int)(__float_as_uint(s) >> 23) - 127;
+                const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
+                const bool have = c + lane < nchunk;
+                const uint64_t v = have ? u[(size_t)(c + lane) * 3 * kCastBinades + ei] : kTieBit;
+                const uint64_t incl = wave_incl_scan_u64(v & ~kTieBit);
+                const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
+                const bool bad = (v & kTieBit) || S + incl >= (1ull << 24);
+                const uint64_t mask = __ballot(bad);
+                const int L = mask ? (int)__builtin_ctzll(mask) : kWave;
+                const uint64_t adv = L > 0 ? shfl_u64(incl, L - 1) : 0;
+                s = from_mantissa(S + (uint32_t)adv, e);
+                c += L;
+                if (L < kWave) break;  // chunk c has to be drilled (or c == nchunk: the padding lanes are "bad")
+            }
+            if (lane == 0) {
+                sh.s = s;
+                sh.c = c;
+            }
         }
+        __syncthreads();
+        s = sh.s;
+        c = sh.c;
+        if (c >= nchunk) break;
         const int cpx = min(kChunkPx, npx - c * kChunkPx);
-        s = drill<kRunPx>(chan, c * kChunkPx, cpx, s, tab, &row[0][0], cached,
-                          (long long)(gridDim.y - 1 - b) * npx + (npx - c * kChunkPx - cpx));
+        const bool more_after = b + 1 < (int)gridDim.y || c * kChunkPx + cpx < npx;  // pixels of the buffer behind this chunk
+        s = drill_block(chan, c * kChunkPx, cpx, s, tbl, sh, more_after);  // (ends in a barrier: sh.s may be written again)
         ++c;
     }
-    if (lane == 0) sums[b * 3 + ch] = s;
+    if (t == 0) sums[b * 3 + ch] = s;
 }
 
 // mean = float32(sum / count) with the division done in float64 (NumPy's _mean: true_divide of a float32
@@ -416,7 +452,13 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     UWIE_LAUNCH(k_chunk_ulps, dim3(cdiv(s.B * nchunk, kUlpChunks)), dim3(256), 0, st, hist2, ties, ctx->d_cast, s.B * nchunk, nb,
                 ulps);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(64), 0, st, d_in, ulps, ctx->d_cast, npx, nchunk, sums);
+    constexpr size_t kResolveLds = (size_t)256 * kTblCols * sizeof(uint64_t);  // 71680 B: asked for once per context
+    if (!ctx->attr_cast_resolve) {
+        UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cast_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kResolveLds));
+        ctx->attr_cast_resolve = true;
+    }
+    UWIE_LAUNCH(k_cast_resolve, dim3(3, s.B), dim3(kResolveThreads), kResolveLds, st, d_in, ulps, ctx->d_cast, npx, nchunk, sums);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_cast_decide, dim3(cdiv(s.B, 64)), dim3(64), 0, st, sums, s.B, npx, d_kind, d_mean);
     UWIE_LAUNCH_CHECK();

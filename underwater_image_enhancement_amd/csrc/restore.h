@@ -37,6 +37,10 @@ struct RestoreImgT {  // per image, in registers
             a[c] = S.A[b * 3 + c];
             att[c] = px_atten(k, c);
         }
+        // (Round 3, from the ISA: the selects between a[0..2] / att[0..2] below become selects between their ADDRESSES, which
+        // keeps this struct in 40 bytes of scratch memory and reloads a[] from there in the callers' loops.  Building the
+        // table from scalars instead keeps it in registers, changes no kernel's time (A/B, 4K x 64) -- and pushes
+        // k_stretch_lab_lut<1, 256> over its 102-register budget: its spilled build gave wrong bytes, so this stays.)
         if (TAB) {
             for (int i = threadIdx.x; i < 768; i += blockDim.x) {
                 const int c = i >> 8;
