@@ -13,9 +13,8 @@ for sub in "ab":
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:60]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("uwie::", "").split("(")[0][:60]
             if "${KFILTER:-guided}" not in k: continue
-            k = k[:60]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         for k, v in acc.items():
             print(k, {c: "%.4g" % x for c, x in v.items()})

@@ -487,33 +487,42 @@ __device__ __forceinline__ void tail_wave_sync()
 }
 
 // rows x rowbytes bytes (global, row pitch `pitch`) -> dense LDS, by the `nl` lanes of a quadrant (this one is `ql`):
-// dword loads, up to eight in flight per lane; (row, dword) advance without a division per element
-__device__ void tail_stage(const uint8_t *__restrict__ src, size_t pitch, int rows, int rowbytes, uint8_t *dst, int ql, int nl)
+// dword loads, eight in flight per lane; (row, dword) advance without a division per element.
+// The loads are unconditional (round 3): a row's last, partial dword is fetched as the row's last four bytes and shifted,
+// rows past the end re-read the last row -- a load under a branch gets its own s_waitcnt vmcnt(0), which made every one of
+// the eight a round trip of its own (14 us to stage 96 KB at the first tail level).  Rows shorter than four bytes (one
+// RGB pixel, up to three gray ones) keep the byte loads.
+__device__ void tail_stage(const uint8_t *__restrict__ src, size_t pitch, int rows_, int rowbytes_, uint8_t *dst, int ql, int nl)
 {
+    // (the quadrant's size sits in vector registers -- it was selected per wavefront -- so the compiler would predicate on
+    // it lane by lane: readfirstlane makes the branch below a scalar one)
+    const int rows = __builtin_amdgcn_readfirstlane(rows_), rowbytes = __builtin_amdgcn_readfirstlane(rowbytes_);
     const int dpr = (rowbytes + 3) >> 2, total = rows * dpr;
     const int ystep = nl / dpr, dstep = nl - ystep * dpr;
     int y = ql / dpr, d = ql - y * dpr;
-    for (int base = 0; base < total; base += 8 * nl) {
-        uint32_t v[8];
-        int off[8], nb[8];
+    if (rowbytes >= 4) {
+        for (int base = 0; base < total; base += 8 * nl) {
+            uint32_t v[8];
+            int off[8], nb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (base + u * nl >= total) { nb[u] = 0; continue; }  // (uniform)
-            const int bx = 4 * d;
-            nb[u] = y < rows ? min(4, rowbytes - bx) : 0;
-            off[u] = y * rowbytes + bx;
-            const uint8_t *p = src + (size_t)y * pitch + bx;
-            v[u] = 0;
-            if (nb[u] == 4) v[u] = *reinterpret_cast<const u32_unaligned *>(p);
-            else
-                for (int j = 0; j < nb[u]; ++j) v[u] |= (uint32_t)p[j] << (8 * j);
-            y += ystep;
-            d += dstep;
-            if (d >= dpr) { d -= dpr; ++y; }
+            for (int u = 0; u < 8; ++u) {
+                const int bx = 4 * d, cx = min(bx, rowbytes - 4);
+                nb[u] = (base + u * nl < total && y < rows) ? min(4, rowbytes - bx) : 0;
+                off[u] = y * rowbytes + bx;
+                v[u] = *reinterpret_cast<const u32_unaligned *>(src + (size_t)min(y, rows - 1) * pitch + cx) >> (8 * (bx - cx));
+                y += ystep;
+                d += dstep;
+                if (d >= dpr) { d -= dpr; ++y; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                for (int j = 0; j < nb[u]; ++j) dst[off[u] + j] = (uint8_t)(v[u] >> (8 * j));
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            for (int j = 0; j < nb[u]; ++j) dst[off[u] + j] = (uint8_t)(v[u] >> (8 * j));
+        return;
+    }
+    for (int i = ql; i < total; i += nl) {  // rows of one to three bytes: dpr == 1
+        const uint8_t *p = src + (size_t)i * pitch;
+        for (int j = 0; j < rowbytes; ++j) dst[i * rowbytes + j] = p[j];
     }
 }
 

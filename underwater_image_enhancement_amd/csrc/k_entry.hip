@@ -211,6 +211,11 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 // with the two table rows in play fetched from global memory at every level and binade change: 142 us of a 1080p frame's
 // 800; the 16384 table look-ups of a drill are LDS-rate bound and a single wavefront gets a fifth of that rate.)
 constexpr int kResolveThreads = 1024, kResolveWaves = kResolveThreads / kWave, kResolvePer = kChunkPx / kResolveThreads;
+// The accumulator leaves a binade every few pixels while it is small (binade e lasts ~2^(e+1) pixels of a mid-gray frame)
+// and a pass of the block costs ~3 us whatever it covers: the first kResolveHead pixels of a frame are added one by one
+// instead (4 ns each: the floats come from LDS four at a time), which replaces the ~11 passes up to s ~ 512.
+constexpr int kResolveHead = 1024;
+static_assert(kResolveHead % kResolvePer == 0 && kResolveHead / kResolvePer <= kWave, "the head's pixels belong to wavefront 0");
 constexpr int kTblCols = kCastBinades + 1;  // entry [v][e+1] exists for every binade (the last column repeats)
 static_assert(kResolvePer == 16, "four packed dwords of pixels per thread");
 
@@ -219,6 +224,7 @@ struct ResolveShared {
     uint64_t wadv[kResolveWaves];   // advance in front of the wavefront's first bad thread
     uint32_t wbad[kResolveWaves];   // that thread's lane (64: none)
     uint32_t px[kResolveWaves][4];  // its sixteen pixels
+    float head[kResolveHead];       // the first pixels of the frame as floats (see drill_block)
     float s;
     int c;
 };
@@ -282,6 +288,18 @@ __device__ float drill_block(const uint8_t *__restrict__ chan, int p0, int cnt, 
         return acc;
     };
     int first = 0;
+    if (s < 0.25f) {  // the frame's first drill (s == 0 unless the frame starts with black pixels)
+        if (t < kResolveHead / kResolvePer) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sh.head[t * kResolvePer + i] = px_norm_fast((vals[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        }
+        __syncthreads();
+        for (int i = 0; i < kResolveHead; i += 4) {  // (every thread adds them: s stays uniform without a broadcast)
+            const float4 x = *reinterpret_cast<const float4 *>(&sh.head[i]);
+            s = (((s + x.x) + x.y) + x.z) + x.w;
+        }
+        first = kResolveHead / kResolvePer;
+    }
     while (first < kResolveThreads) {
         int L;
         if (s >= 0.25f) {
@@ -369,13 +387,22 @@ __global__ void __launch_bounds__(kResolveThreads) k_cast_resolve(const uint8_t 
     const uint64_t *u = ulps + (((size_t)b * nchunk) * 3 + ch) * kCastBinades;
     float s = 0.0f;
     int c = 0;
+    // Wavefront 0 fetches the ulp counts it will most likely need after a drill -- chunks c+1.. in the NEXT binade (a chunk is
+    // drilled because the accumulator leaves its binade there; a tie leaves it where it was) -- before the drill, so the
+    // walk that follows does not start with a memory round trip (~1.5 us, ~24 times per channel).
+    uint64_t v_pre = 0;
+    int pre_c = -1, pre_ei = -1;
     for (;;) {
         if (t < kWave) {  // chunks passed in closed form
+            int ei = -1;
             while (c < nchunk && s >= 0.25f) {
                 const int e = (int)(__float_as_uint(s) >> 23) - 127;
-                const int ei = min(e - kCastBinadeMin, kCastBinades - 1);
+                ei = min(e - kCastBinadeMin, kCastBinades - 1);
                 const bool have = c + lane < nchunk;
-                const uint64_t v = have ? u[(size_t)(c + lane) * 3 * kCastBinades + ei] : kTieBit;
+                uint64_t v;
+                if (c == pre_c && ei == pre_ei) v = v_pre;  // (uniform)
+                else v = have ? u[(size_t)(c + lane) * 3 * kCastBinades + ei] : kTieBit;
+                pre_c = -1;
                 const uint64_t incl = wave_incl_scan_u64(v & ~kTieBit);
                 const uint32_t S = (__float_as_uint(s) & 0x7fffffu) | 0x800000u;
                 const bool bad = (v & kTieBit) || S + incl >= (1ull << 24);
@@ -385,6 +412,11 @@ __global__ void __launch_bounds__(kResolveThreads) k_cast_resolve(const uint8_t 
                 s = from_mantissa(S + (uint32_t)adv, e);
                 c += L;
                 if (L < kWave) break;  // chunk c has to be drilled (or c == nchunk: the padding lanes are "bad")
+            }
+            if (c < nchunk && ei >= 0) {
+                pre_c = c + 1;
+                pre_ei = min(ei + 1, kCastBinades - 1);
+                v_pre = pre_c + lane < nchunk ? u[(size_t)(pre_c + lane) * 3 * kCastBinades + pre_ei] : kTieBit;
             }
             if (lane == 0) {
                 sh.s = s;
