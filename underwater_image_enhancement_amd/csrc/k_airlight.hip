@@ -487,37 +487,61 @@ __device__ __forceinline__ void tail_wave_sync()
 }
 
 // rows x rowbytes bytes (global, row pitch `pitch`) -> dense LDS, by the `nl` lanes of a quadrant (this one is `ql`):
-// dword loads, eight in flight per lane; (row, dword) advance without a division per element.
-// The loads are unconditional (round 3): a row's last, partial dword is fetched as the row's last four bytes and shifted,
-// rows past the end re-read the last row -- a load under a branch gets its own s_waitcnt vmcnt(0), which made every one of
-// the eight a round trip of its own (14 us to stage 96 KB at the first tail level).  Rows shorter than four bytes (one
-// RGB pixel, up to three gray ones) keep the byte loads.
-__device__ void tail_stage(const uint8_t *__restrict__ src, size_t pitch, int rows_, int rowbytes_, uint8_t *dst, int ql, int nl)
+// dword loads; (row, dword) advance without a division per element.
+// Round 3: (a) the loads are unconditional -- a row's last, partial dword is fetched as the row's last four bytes and
+// shifted, positions past the end re-read the last row: a load under a branch gets its own s_waitcnt vmcnt(0), which made
+// every load a round trip of its own; (b) a dword that lands 4-byte aligned in the dense LDS image is stored as one
+// instead of four bytes.  Rows shorter than four bytes
+// (one RGB pixel, up to three gray ones) keep the byte loads.
+struct StageCursor {
+    int y, d;
+};
+template <int N>
+__device__ __forceinline__ void tail_stage_n(const uint8_t *__restrict__ src, size_t pitch, int rows, int rowbytes, uint8_t *dst,
+                                             int first, int nl, int total, int dpr, int ystep, int dstep, StageCursor &cur)
+{
+    uint32_t v[N];  // (only the data stays in registers: the store loop walks the positions again)
+    StageCursor ld = cur;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int bx = 4 * ld.d, cx = min(bx, rowbytes - 4);
+        v[u] = *reinterpret_cast<const u32_unaligned *>(src + (size_t)min(ld.y, rows - 1) * pitch + cx) >> (8 * (bx - cx));
+        ld.y += ystep;
+        ld.d += dstep;
+        if (ld.d >= dpr) { ld.d -= dpr; ++ld.y; }
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int bx = 4 * cur.d;
+        const int nb = (first + u * nl < total && cur.y < rows) ? min(4, rowbytes - bx) : 0, off = cur.y * rowbytes + bx;
+        if (nb == 4 && !(off & 3)) *reinterpret_cast<uint32_t *>(dst + off) = v[u];
+        else
+            for (int j = 0; j < nb; ++j) dst[off + j] = (uint8_t)(v[u] >> (8 * j));
+        cur.y += ystep;
+        cur.d += dstep;
+        if (cur.d >= dpr) { cur.d -= dpr; ++cur.y; }
+    }
+}
+
+__device__ __forceinline__ void tail_stage(const uint8_t *__restrict__ src, size_t pitch, int rows_, int rowbytes_, uint8_t *dst, int ql,
+                                           int nl)
 {
     // (the quadrant's size sits in vector registers -- it was selected per wavefront -- so the compiler would predicate on
-    // it lane by lane: readfirstlane makes the branch below a scalar one)
+    // it lane by lane: readfirstlane makes the branches below scalar ones)
     const int rows = __builtin_amdgcn_readfirstlane(rows_), rowbytes = __builtin_amdgcn_readfirstlane(rowbytes_);
     const int dpr = (rowbytes + 3) >> 2, total = rows * dpr;
-    const int ystep = nl / dpr, dstep = nl - ystep * dpr;
-    int y = ql / dpr, d = ql - y * dpr;
     if (rowbytes >= 4) {
-        for (int base = 0; base < total; base += 8 * nl) {
-            uint32_t v[8];
-            int off[8], nb[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int bx = 4 * d, cx = min(bx, rowbytes - 4);
-                nb[u] = (base + u * nl < total && y < rows) ? min(4, rowbytes - bx) : 0;
-                off[u] = y * rowbytes + bx;
-                v[u] = *reinterpret_cast<const u32_unaligned *>(src + (size_t)min(y, rows - 1) * pitch + cx) >> (8 * (bx - cx));
-                y += ystep;
-                d += dstep;
-                if (d >= dpr) { d -= dpr; ++y; }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                for (int j = 0; j < nb[u]; ++j) dst[off[u] + j] = (uint8_t)(v[u] >> (8 * j));
-        }
+        const int ystep = nl / dpr, dstep = nl - ystep * dpr;
+        StageCursor cur;
+        cur.y = ql / dpr;
+        cur.d = ql - cur.y * dpr;
+        int first = ql;
+        // eight loads in flight per lane (a 1024-thread block has 128 registers per lane: 24 at once -- the whole of a
+        // first-level quadrant in one round trip -- spilled 200 of them)
+        for (; first - ql + 4 * nl < total; first += 8 * nl)  // (uniform trip counts)
+            tail_stage_n<8>(src, pitch, rows, rowbytes, dst, first, nl, total, dpr, ystep, dstep, cur);
+        for (; first - ql < total; first += 4 * nl)
+            tail_stage_n<4>(src, pitch, rows, rowbytes, dst, first, nl, total, dpr, ystep, dstep, cur);
         return;
     }
     for (int i = ql; i < total; i += nl) {  // rows of one to three bytes: dpr == 1
