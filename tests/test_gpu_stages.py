@@ -67,6 +67,10 @@ def test_cast_classify_matches_numpy_sequential_mean(dev, orc, frames, golden):
     cases["zeros_64x64"] = np.zeros((64, 64, 3), np.uint8)
     cases["white_257x129"] = np.full((257, 129, 3), 255, np.uint8)  # (a ragged last chunk, every add of one size)
     cases["odd_1031x517"] = rng.integers(0, 256, (1031, 517, 3), dtype=np.uint8)
+    cases["one_chunk_128x128"] = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)   # exactly 16384 pixels
+    cases["chunk_plus_one_5x3277"] = rng.integers(0, 256, (5, 3277, 3), dtype=np.uint8)  # 16385: a one-pixel last chunk
+    cases["bright_start_then_black"] = np.concatenate([np.full((40, 500, 3), 255, np.uint8), np.zeros((300, 500, 3), np.uint8)])
+    cases["black_start_then_noise"] = np.concatenate([np.zeros((300, 500, 3), np.uint8), rng.integers(0, 256, (200, 500, 3), dtype=np.uint8)])
     cases["dark_4k"] = (rng.random((2160, 3840, 3)) < 0.3).astype(np.uint8) * rng.integers(0, 4, (2160, 3840, 3), dtype=np.uint8)
     cases["steps_2k"] = np.repeat(np.arange(0, 256, dtype=np.uint8), 3 * 2048 * 4).reshape(2048, 1024, 3)  # long constant runs
     for tag in GOLDEN_TAGS:
