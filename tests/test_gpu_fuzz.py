@@ -126,3 +126,19 @@ def test_f32t_transmission_stated_tolerance(uw, orc):
     # the mode is a permission, not an obligation: windows / frames the wavefront kernels do not take keep float64
     odd = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
     assert np.array_equal(uw.enhance(odd, strategy=2, inter_dtype=_lib.INTER_F32T), orc.enhance_u8(odd, 2))
+
+
+def test_boundary_value_frame_from_the_soak_run(uw, orc):
+    """profiles/soak.py (9000 random cases, seed 12) found ONE byte that differs from the oracle by more than 1 LSB: frame 977,
+    strategy 2, pixel (139, 121) red, 136 against 134.  The frame is kept as a fixture because it pins the mechanism: the
+    default guided filter sums its windows in a free order (t within 1e-11 of cv2.boxFilter's running sums, observed 1e-15);
+    where the exact value sits on a truncation boundary ahead of CLAHE the last bit of t decides the byte, and CLAHE's local
+    slope (here 2) scales the step.  With gf_exact=1 (cv2.boxFilter's own order) the output is identical; the default is
+    allowed this one byte and no more.  DESIGN.md section 6 states the rate (1 byte in ~1e9)."""
+    import os
+
+    u8 = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_seed12_frame977.npz"))["u8"]
+    want = orc.enhance_u8(u8, 2)
+    assert np.array_equal(uw.enhance(u8, strategy=2, gf_exact=1), want)
+    d = np.abs(uw.enhance(u8, strategy=2).astype(int) - want.astype(int))
+    assert np.count_nonzero(d) <= 1 and d.max() <= 2
