@@ -8,21 +8,18 @@
 //   * inside one binade [2^e, 2^(e+1)) of the accumulator s, fl(s + x) == s + RN_ulp(x) exactly, so a run
 //     of pixels advances s by an INTEGER number of ulps that depends only on the histogram of the run
 //     (inputs are u8/255: 256 distinct values);
-//   * k_chunk_hist takes one 3x256 histogram per 16384-pixel chunk (one streaming pass over the frame) and turns it
-//     into the chunk's ulp advance for every binade of the accumulator;
-//   * k_cast_resolve (one wavefront per image and channel) walks the chunks 64 at a time: a prefix scan over
-//     their ulp advances finds the first chunk that leaves the binade or holds a round-half-even tie, s jumps
-//     there in closed form, and that chunk is drilled: 64 lanes x 256-pixel runs, the same scan, then 64 x 4
-//     pixels, and plain sequential float adds only for the last 4 pixels around the event.
+//   * k_chunk_hist takes one 3x256 histogram per 16384-pixel chunk (one streaming pass over the frame) and k_chunk_ulps
+//     turns it into the chunk's ulp advance for every binade of the accumulator;
+//   * k_cast_resolve (one workgroup per image and channel) walks the chunks 64 at a time: a prefix scan over their ulp
+//     advances finds the first chunk that leaves the binade or holds a round-half-even tie, s jumps there in closed
+//     form, and that chunk is drilled by the whole workgroup: 1024 threads x 16 pixels, the same scan on two levels, and
+//     plain sequential float adds only for the 16 pixels around the event (and for the frame's first 1024 pixels).
 #include "common.h"
 #include "devutil.h"
-
-#include <type_traits>
 
 namespace uwie {
 
 constexpr int kChunkPx = 16384;  // pixels per histogram chunk
-constexpr int kRunPx = 256;      // pixels per lane inside a drilled chunk (64 * 256 = kChunkPx)
 
 // Per chunk, channel and binade e of the accumulator: the number of ulps the chunk advances it by,
 // D = sum_k hist[k] * RN(x_k / ulp_e), with bit 63 set when some present value ties (x_k / ulp_e = n + 1/2: the result
