@@ -201,3 +201,30 @@ def test_no_v_ashr_pk_in_the_byte_saturating_kernels(tmp_path):
         text = out.read_text()
         assert "s_endpgm" in text
         assert "v_ashr_pk" not in text, f"{name}: v_ashr_pk_* selected"
+
+
+def test_cast_detection_kernel_assumptions():
+    """The arithmetic facts k_entry.hip's round-3 kernels lean on, restated with NumPy (no GPU):
+    * R_e(v) = RN(x_v / ulp_e) < 2^26 for every byte value and binade e >= -2, so R = hi * 2^13 + lo with 13-bit halves and,
+      with at most 16384 pixels per chunk, both partial sums of k_chunk_ulps stay below 2^27 (v_dot2_u32_u16 operands are
+      16 bits, its accumulator 32);
+    * a byte value ties (x_v / ulp_e = n + 1/2) in at most ONE binade (CastTables::tiebin);
+    * a lane column of k_chunk_hist receives at most 512 + 1 pixels of a chunk: 10-bit fields cannot overflow;
+    * 16 table entries of k_cast_resolve (count below 2^26, tie flag at bit 40) cannot carry into each other."""
+    import numpy as np
+
+    x = (np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float64)
+    ties = np.zeros((34, 256), bool)
+    for ei, e in enumerate(range(-2, 32)):
+        y = x / 2.0 ** (e - 23)  # exact: a power of two
+        r = np.floor(y)
+        frac = y - r
+        ties[ei] = frac == 0.5
+        r = np.where(frac > 0.5, r + 1, r)
+        assert r.max() < 2 ** 26
+        lo, hi = r.astype(np.int64) & 0x1FFF, r.astype(np.int64) >> 13
+        assert hi.max() < 2 ** 13 and 16384 * max(lo.max(), hi.max()) < 2 ** 27
+        assert np.array_equal((hi << 13) + lo, r.astype(np.int64))
+    assert ties.sum(axis=0).max() <= 1 and not ties[:, 0].any()
+    assert 16384 // 32 + 3 < 1024
+    assert 16 * (2 ** 26) < 2 ** 40 and 16 < 2 ** (64 - 40)
