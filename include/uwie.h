@@ -121,7 +121,8 @@ int uwie_params_init(uwie_params *p, int surface, int strategy);
 /* Route selectors of a context: which of several equivalent routes a stage takes where uwie_params has no say (results are
  * the same bytes on every route; the parity tests force the fallback routes this way, profiles/ scripts compare them).
  * Names (default): gf_pipe (1), gf_split (1), gf_bands (0 = chosen from the job), select_generic (0), restore_store (0),
- * lin_predict3 (0), lin_cap (0 = default), lin_no_predict (0), lin_predict_shift (0), streams (1; 2 .. 4 = sub-batches on
+ * lin_predict3 (0), lin_cap (0 = default), lin_no_predict (0), lin_predict_shift (0), q_hist (1: quadtree levels decided
+ * from byte histograms where the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used), streams (1; 2 .. 4 = sub-batches on
  * internal streams), canny_prepass (1).  An environment variable UWIE_<NAME> sets the initial value; it is read once, in
  * uwie_create -- no entry point reads the environment.  Unknown names are an error. */
 int uwie_set_tuning(uwie_ctx *ctx, const char *name, int value);

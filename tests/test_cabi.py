@@ -228,3 +228,14 @@ def test_cast_detection_kernel_assumptions():
     assert ties.sum(axis=0).max() <= 1 and not ties[:, 0].any()
     assert 16384 // 32 + 3 < 1024
     assert 16 * (2 ** 26) < 2 ** 40 and 16 < 2 ** (64 - 40)
+
+
+def test_gray_quantisation_identities():
+    """k_q_hist writes the 8-bit gray plane from the bytes themselves: (x * 255).astype(u8) of the normalised value is
+    the byte again, and of the attenuated value (x * 0.85) it is 17 u // 20 -- NumPy's float32 arithmetic, all 256 bytes."""
+    import numpy as np
+
+    u = np.arange(256)
+    x = u.astype(np.float32) / np.float32(255.0)
+    assert np.array_equal((x * np.float32(255.0)).astype(np.uint8), u)
+    assert np.array_equal(((x * np.float32(0.85)) * np.float32(255.0)).astype(np.uint8), u * 17 // 20)

@@ -418,6 +418,49 @@ def test_atmospheric_light_matches_oracle_trace(dev, orc, frames):
         same(A[0].cpu().numpy(), np.asarray(want_A))
 
 
+def test_quadtree_levels_decided_from_histograms_equal_the_exact_kernels(dev, orc):
+    """Round 3: a launched quadtree level is decided from byte histograms of the quadrants when the score intervals
+    separate (k_q_hist / k_q_decide), by the exact NumPy-order kernels otherwise (tuning q_hist = 2 forces that, 0 switches
+    the histograms off; a trace request takes the exact kernels too).  All routes must return the same atmospheric light --
+    smooth frames (decided), uniform noise (near ties), flat and two-level frames (exact ties: first maximum wins), a frame
+    whose bright quadrant is the last one, every cast kind, a batch mixing them -- and the oracle's."""
+    import torch
+
+    rng = np.random.default_rng(2718)
+    H, W = 460, 700
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    f = (0.3 + 0.5 * np.exp(-((xx - 520) ** 2 + (yy - 330) ** 2) / 30000.0))[:, :, None] * np.array([0.45, 0.85, 0.8])
+    frames.append(np.clip(255 * (f + rng.normal(0, 0.02, f.shape)), 0, 255).astype(np.uint8))
+    frames.append(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+    frames.append(np.full((H, W, 3), 97, np.uint8))
+    two = np.full((H, W, 3), 60, np.uint8)
+    two[H // 2:, W // 2:] = 200
+    frames.append(two)
+    frames.append(np.clip(rng.normal(128, 3, (H, W, 3)), 0, 255).astype(np.uint8))
+    frames.append(np.zeros((H, W, 3), np.uint8))
+    batch = np.stack(frames)
+    for kind_id in (0, 1, 2):
+        kk = torch.full((len(frames),), kind_id, dtype=torch.int32, device=dev.torch_device)
+        got = {}
+        for q_hist in (1, 0, 2):
+            with dev.tuning(q_hist=q_hist):
+                got[q_hist] = dev.atmospheric_light(dev.tensor(batch), kk).cpu().numpy()
+        assert np.array_equal(got[1], got[0]) and np.array_equal(got[1], got[2]), kind_id
+        for i, u8 in enumerate(frames):
+            xc = orc.correct_cast(orc.normalise_u8(u8), KINDS[kind_id])
+            same(got[1][i], np.asarray(orc.atmospheric_light(xc, 1)))
+    # one large frame: four launched levels at 1500 x 2100, every one of them through both routes
+    big = np.clip(255 * ((0.35 + 0.4 * np.sin(np.mgrid[0:1500, 0:2100][1] / 300.0) * np.cos(np.mgrid[0:1500, 0:2100][0] / 170.0))[:, :, None]
+                         * np.array([0.5, 0.9, 0.8]) + rng.normal(0, 0.02, (1500, 2100, 3))), 0, 255).astype(np.uint8)
+    kk = torch.zeros(1, dtype=torch.int32, device=dev.torch_device)
+    res = []
+    for q_hist in (1, 0, 2):
+        with dev.tuning(q_hist=q_hist):
+            res.append(dev.atmospheric_light(dev.tensor(big[None]), kk).cpu().numpy())
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
 def test_atmospheric_light_other_leaf_sizes(dev, orc):
     """min_size > 1 (the quadtree's leaf size, S6:49): the walk stops earlier -- inside the launched levels, at the hand-over
     to k_q_tail, or inside it -- and the brightest pixel is taken over a larger leaf."""

@@ -63,7 +63,7 @@ struct KnobName { const char *name; int Tuning::*field; };
 const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::gf_split}, {"gf_bands", &Tuning::gf_bands},
                            {"select_generic", &Tuning::select_generic}, {"restore_store", &Tuning::restore_store},
                            {"lin_predict3", &Tuning::lin_predict3}, {"lin_cap", &Tuning::lin_cap},
-                           {"lin_no_predict", &Tuning::lin_no_predict}, {"lin_predict_shift", &Tuning::lin_predict_shift},
+                           {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
                            {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only

@@ -96,6 +96,7 @@ struct Tuning {
     int lin_predict3 = 0;       // strategy 3: predicted windows as for strategies 1-2
     int lin_cap = 0;            // candidate list capacity (0: default; small values force the overflow fallback)
     int lin_no_predict = 0;     // no predicted windows: always the collecting sweep
+    int q_hist = 1;             // quadtree levels decided from byte histograms when the interval test allows (2: never allows)
     int lin_predict_shift = 0;  // predicted windows moved by this many bins (large: every prediction misses)
     int streams = 1;            // uwie_enhance_u8: sub-batches on this many internal streams (1 .. 4)
     int canny_prepass = 1;      // quadtree: the streaming "any strong pixel?" pass before Canny

@@ -35,6 +35,8 @@ struct LevelBufs {
     float *mean;       // [4B][3] means
     float *vtot;       // [4B][3] sums of squared deviations
     uint32_t *edges;   // [4B] Canny edge counts
+    uint32_t *hist;    // [4B][3][256] byte histograms of the quadrants (k_q_hist)
+    uint8_t *skip;     // [B] 1: the level was decided from the histograms, the exact kernels return at once
 };
 
 __global__ void k_init_blocks(Region *blk, int B, int H, int W)
@@ -302,10 +304,12 @@ __global__ void __launch_bounds__(64) k_q_chunk_sums(const uint8_t *__restrict__
                                                      const Region *__restrict__ regs, const float *__restrict__ mean,
                                                      int H, int W, int maxChunks, float *__restrict__ csum,
                                                      const float *__restrict__ csum_in = nullptr,
-                                                     uint8_t *__restrict__ gray_out = nullptr, int gray_shift = 15)
+                                                     uint8_t *__restrict__ gray_out = nullptr, int gray_shift = 15,
+                                                     const uint8_t *__restrict__ skip = nullptr)
 {
     const int reg = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
     const Region r = regs[reg];
+    if (skip && skip[r.img]) return;  // decided from the histograms (k_q_decide)
     const int n = r.rows * r.cols;
     const int c0 = ci * kNpChunk;
     if (c0 >= n) return;
@@ -374,6 +378,246 @@ __global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ reg
     if (!VAR) mean[reg * 3 + lane] = (float)((double)acc / (double)n);
 }
 
+// The greedy step (six_stadigy.py:100-111): quadrant `arg` becomes the block, its quadrants the next level's regions
+// (what k_make_quadrants would write) with zeroed edge counters.  One lane.
+__device__ void q_descend(Region *__restrict__ blk, Region *__restrict__ regs, uint32_t *__restrict__ edges, int b, int arg, int min_size)
+{
+    const Region k = regs[b * 4 + arg];
+    blk[b] = k;
+    const bool leaf = k.rows <= min_size || k.cols <= min_size;  // six_stadigy.py:76
+    const int mr = k.rows / 2, mc = k.cols / 2;                 // six_stadigy.py:85-86
+    Region q[4] = {{b, k.y0, k.x0, mr, mc},
+                   {b, k.y0, k.x0 + mc, mr, k.cols - mc},
+                   {b, k.y0 + mr, k.x0, k.rows - mr, mc},
+                   {b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc}};
+    for (int i = 0; i < 4; ++i) {
+        if (leaf) q[i].rows = q[i].cols = 0;
+        regs[b * 4 + i] = q[i];
+        edges[b * 4 + i] = 0;
+    }
+}
+
+// ---- a level decided from byte histograms (round 3) ------------------------------------------------------------------
+// compute_Q's score of a quadrant is a function of sums over its pixels, and a pixel's contribution only depends on its
+// byte: the EXACT sums (sum x, sum (x - m)^2 per channel) follow from a 3 x 256 histogram of the quadrant -- one pass over
+// the RGB bytes where NumPy's order needs two, and a streaming one (k_q_hist: the lane-column histogram words of
+// k_chunk_hist; on level 0 it writes the gray plane on the way).  The reference's float32 pairwise sums differ from the
+// exact ones by a bounded amount, so k_q_decide evaluates each quadrant's score as an INTERVAL that contains the
+// reference's value; when the best quadrant's interval lies above the other three the argmax is known and the level is
+// decided (results identical by construction), otherwise -- near ties, or when the caller wants the scores themselves
+// (trace) -- the image is left to the exact kernels (k_q_chunk_sums x 2, k_q_select), which return at once for every
+// decided image.  Bounds: a chunk's pairwise sum of non-negative terms is within 35 u of exact (15 sequential adds per
+// accumulator, 3 + 7 tree levels up to the 8192-element buffer, the unrolled tail), the sequential total over nch chunks
+// adds (nch - 1) u, u = 2^-24; the squared deviations add 3 u per element and n (m~ - m)^2 from the rounded mean; every
+// float32 operation of the score adds u.  All of them are taken 1.25 x.
+constexpr int kQHistCols = 32, kQHistFold = 31;  // fold the 10-bit fields after 31 steps: 31 * 4 pixels * 8 threads per column
+static_assert(kQHistFold * 4 * (256 / kQHistCols) < 1024, "10-bit fields");
+
+template <bool GRAY>
+__global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                const Region *__restrict__ regs, int H, int W, uint32_t *__restrict__ hist,
+                                                uint8_t *__restrict__ gray_out, int gray_shift)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t h[256 * kQHistCols];
+    __shared__ uint32_t cnt[768];
+    const int reg = blockIdx.y, tid = threadIdx.x;
+    const Region r = regs[reg];
+    if (r.rows <= 0 || r.cols <= 0) return;
+    const int rpb = (r.rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int y_lo = blockIdx.x * rpb, y_hi = min(r.rows, y_lo + rpb);
+    if (y_lo >= y_hi) return;
+    for (int i = tid; i < 256 * kQHistCols / 4; i += 256) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 768; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const int knd = kind ? kind[r.img] : 0;
+    const uint8_t *img = in + (size_t)r.img * H * W * 3;
+    uint8_t *gray = GRAY ? gray_out + (size_t)r.img * H * W : nullptr;
+    const uint32_t colb = (uint32_t)(tid & (kQHistCols - 1)) * 4u;
+    char *hb = reinterpret_cast<char *>(h);
+    auto bump = [&](uint32_t moved, uint32_t inc) { atomicAdd(reinterpret_cast<uint32_t *>(hb + ((moved & 0x7f80u) | colb)), inc); };
+    constexpr uint32_t kR = 1u, kG = 1u << 10, kB = 1u << 20;
+    auto fold = [&]() {  // all threads; thread v folds the 32 columns of value v into the 32-bit totals and clears them
+        __syncthreads();
+        uint32_t cr = 0, cg = 0, cb = 0;
+#pragma unroll 8
+        for (int k = 0; k < kQHistCols; ++k) {
+            uint32_t &w = h[tid * kQHistCols + ((tid + k) & (kQHistCols - 1))];
+            cr += w & 1023u;
+            cg += (w >> 10) & 1023u;
+            cb += w >> 20;
+            w = 0;
+        }
+        cnt[tid] += cr; cnt[256 + tid] += cg; cnt[512 + tid] += cb;
+        __syncthreads();
+    };
+    // (x * 255).astype(u8) of the normalised, colour-corrected value without floating point: for every byte u
+    //     quant_u8(fl(u / 255) * 255) == u     and     quant_u8(fl(fl(u / 255) * 0.85f) * 255) == 17 u / 20
+    // (tests/test_cabi.py checks both against NumPy's float32 arithmetic for all 256 bytes)
+    const bool t0 = px_atten(knd, 0), t1 = px_atten(knd, 1), t2 = px_atten(knd, 2);
+    auto gray4 = [&](uint32_t rr, uint32_t gg, uint32_t bb) {
+        return gray_fixed(t0 ? rr * 17u / 20u : rr, t1 ? gg * 17u / 20u : gg, t2 ? bb * 17u / 20u : bb, gray_shift);
+    };
+    const int G = (r.cols + 3) >> 2, trips = (G + 255) >> 8;  // groups of four pixels per row; block-uniform trips per row
+    // A step = one group of four pixels per thread.  The 12 bytes of the NEXT step are loaded (unconditionally, position
+    // clamped into the row: see k_chunk_hist) into a second register set before this step's atomics.
+    struct Cursor {
+        int y, t;
+    };
+    const bool wide = r.cols >= 4;  // (uniform)
+    auto advance = [&](Cursor &c) {
+        if (++c.t == trips) { c.t = 0; ++c.y; }
+    };
+    auto fetch = [&](const Cursor &c, uint32_t (&d)[3]) {
+        if (!wide) return;
+        const int x = min(4 * (c.t * 256 + tid), r.cols - 4), y = min(c.y, y_hi - 1);
+        const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(img + ((size_t)(r.y0 + y) * W + r.x0 + x) * 3);
+        d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+    };
+    int steps = 0;
+    auto body = [&](const Cursor &c, const uint32_t (&d)[3]) {
+        if (c.y >= y_hi) return;  // (uniform)
+        const int x = 4 * (c.t * 256 + tid), n = min(4, r.cols - x);
+        if (n == 4) {
+            const uint32_t c0 = d[0], c1 = d[1], c2 = d[2];
+            // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            bump(c0 << 7, kR); bump(c0 >> 1, kG); bump(c0 >> 9, kB);
+            bump(c0 >> 17, kR); bump(c1 << 7, kG); bump(c1 >> 1, kB);
+            bump(c1 >> 9, kR); bump(c1 >> 17, kG); bump(c2 << 7, kB);
+            bump(c2 >> 1, kR); bump(c2 >> 9, kG); bump(c2 >> 17, kB);
+            if constexpr (GRAY) {
+                const uint32_t g4 = gray4(c0 & 255, (c0 >> 8) & 255, (c0 >> 16) & 255) |
+                                    gray4(c0 >> 24, c1 & 255, (c1 >> 8) & 255) << 8 |
+                                    gray4((c1 >> 16) & 255, c1 >> 24, c2 & 255) << 16 |
+                                    gray4((c2 >> 8) & 255, (c2 >> 16) & 255, c2 >> 24) << 24;
+                *reinterpret_cast<u32_unaligned *>(gray + (size_t)(r.y0 + c.y) * W + r.x0 + x) = g4;
+            }
+        } else {
+            const uint8_t *row = img + ((size_t)(r.y0 + c.y) * W + r.x0) * 3;
+            for (int j = 0; j < n; ++j) {
+                const uint8_t *p = row + (size_t)(x + j) * 3;
+                bump((uint32_t)p[0] << 7, kR); bump((uint32_t)p[1] << 7, kG); bump((uint32_t)p[2] << 7, kB);
+                if constexpr (GRAY) gray[(size_t)(r.y0 + c.y) * W + r.x0 + x + j] = (uint8_t)gray4(p[0], p[1], p[2]);
+            }
+        }
+        if (++steps == kQHistFold) {  // (block-uniform)
+            fold();
+            steps = 0;
+        }
+    };
+    {
+        // kAhead steps per batch, two batches of registers taking turns (a register copy would wait for the loads it copies):
+        // 2 x 48 bytes per thread in flight
+        constexpr int kAhead = 4;
+        uint32_t bufa[kAhead][3] = {}, bufb[kAhead][3] = {};
+        auto fetchN = [&](Cursor c, uint32_t (&d)[kAhead][3]) {
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) {
+                fetch(c, d[i]);
+                advance(c);
+            }
+        };
+        auto bodyN = [&](Cursor c, const uint32_t (&d)[kAhead][3]) {
+#pragma unroll
+            for (int i = 0; i < kAhead; ++i) {
+                body(c, d[i]);
+                advance(c);
+            }
+        };
+        auto skipN = [&](Cursor &c, int n) {
+            for (int i = 0; i < n; ++i) advance(c);
+        };
+        Cursor ca{y_lo, 0}, cb{y_lo, 0};
+        skipN(cb, kAhead);
+        fetchN(ca, bufa);
+        while (ca.y < y_hi) {
+            fetchN(cb, bufb);
+            bodyN(ca, bufa);
+            skipN(ca, 2 * kAhead);
+            fetchN(ca, bufa);
+            bodyN(cb, bufb);
+            skipN(cb, 2 * kAhead);
+        }
+    }
+    fold();
+    for (int i = tid; i < 768; i += 256)
+        if (cnt[i]) atomicAdd(&hist[(size_t)reg * 768 + i], cnt[i]);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wavefront per image: the four quadrants' score intervals from their histograms; decides the level when it can.
+// force_exact: leave every image to the exact kernels (the caller records the scores, or tuning q_hist = 2).
+__global__ void __launch_bounds__(64) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
+                                                 const uint32_t *__restrict__ hist, uint32_t *__restrict__ edges,
+                                                 const int32_t *__restrict__ kind, int min_size, int force_exact,
+                                                 uint8_t *__restrict__ skip)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (regs[b * 4].rows == 0) {  // leaf reached earlier: nothing left to decide
+        if (lane == 0) skip[b] = 1;
+        return;
+    }
+    if (force_exact) {
+        if (lane == 0) skip[b] = 0;
+        return;
+    }
+    const int knd = kind ? kind[b] : 0;
+    constexpr double u = 0x1p-24, kSafe = 1.25;
+    double qlo[4], qhi[4], qmid[4];
+    for (int q = 0; q < 4; ++q) {
+        const Region r = regs[b * 4 + q];
+        const double n = (double)r.rows * (double)r.cols;
+        const int nch = (int)(((long long)r.rows * r.cols + kNpChunk - 1) / kNpChunk);
+        const double eS = kSafe * (nch + 35) * u, eV = kSafe * (nch + 38) * u;
+        double Slo[3], Shi[3], Vlo[3], Vhi[3];
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t *hc = hist + ((size_t)(b * 4 + q) * 3 + c) * 256;
+            const float a = px_atten(knd, c) ? 0.85f : 1.0f;
+            double xs[4], ns[4], part = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = lane + 64 * k;
+                xs[k] = (double)(px_norm_fast((uint32_t)v) * a);  // the element's float32 value, exactly as the sums see it
+                ns[k] = (double)hc[v];
+                part += ns[k] * xs[k];
+            }
+            const double S = wave_sum_f64(part), m = S / n;
+            part = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part += ns[k] * (xs[k] - m) * (xs[k] - m);
+            const double V = wave_sum_f64(part);
+            const double dm = (eS + 2 * u) * fabs(m);  // |m~ - m|: the rounded sum, its division, its conversion to float32
+            Slo[c] = S * (1.0 - eS); Shi[c] = S * (1.0 + eS);
+            Vlo[c] = V * (1.0 - eV); Vhi[c] = (V + n * dm * dm) * (1.0 + eV);
+        }
+        // six_stadigy.py:134-155 in float32: every operation rounds once (u), conversions of n included
+        const double sA = fabs(Shi[0]) + fabs(Shi[1]) + fabs(Shi[2]);
+        const double t1lo = (Slo[0] + Slo[1] + Slo[2]) / (3.0 * n), t1hi = (Shi[0] + Shi[1] + Shi[2]) / (3.0 * n);
+        const double t2lo = (Slo[2] + Slo[1] - 2.0 * Shi[0]) / n, t2hi = (Shi[2] + Shi[1] - 2.0 * Slo[0]) / n;
+        const double t3lo = (Vlo[0] + Vlo[1] + Vlo[2]) / (3.0 * n), t3hi = (Vhi[0] + Vhi[1] + Vhi[2]) / (3.0 * n);
+        const double t4 = (double)edges[b * 4 + q] / n;
+        // rounding of the float32 expression tree: <= 6 operations on terms bounded by these magnitudes
+        const double slack = kSafe * 8.0 * u * (sA / (3.0 * n) + (fabs(Shi[2]) + fabs(Shi[1]) + 2.0 * fabs(Shi[0])) / n + fabs(t3hi)) + 1e-300;
+        qlo[q] = (t1lo + t2lo) - t3hi - t4 - slack;
+        qhi[q] = (t1hi + t2hi) - t3lo - t4 + slack;
+        qmid[q] = 0.5 * (qlo[q] + qhi[q]);
+    }
+    if (lane != 0) return;
+    int arg = 0;
+    for (int q = 1; q < 4; ++q)
+        if (qmid[q] > qmid[arg]) arg = q;
+    bool sure = true;
+    for (int q = 0; q < 4; ++q)
+        if (q != arg && !(qlo[arg] > qhi[q])) sure = false;
+    skip[b] = sure ? 1 : 0;
+    if (sure) q_descend(blk, regs, edges, b, arg, min_size);
+}
+
 // compute_Q's final arithmetic (six_stadigy.py:134-155) and the greedy step (six_stadigy.py:100-111).
 // It also prepares the next level: the chosen block's quadrants (what k_make_quadrants would write) and zeroed edge
 // counters, so a level costs two launches fewer.
@@ -383,10 +627,11 @@ __global__ void __launch_bounds__(64) k_q_combine(const Region *__restrict__ reg
 __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Region *__restrict__ regs,
                                                  const float *__restrict__ csum, const float *__restrict__ csum_var, int maxChunks,
                                                  uint32_t *__restrict__ edges, int B, int level, int min_size,
-                                                 TraceRec *__restrict__ trace)
+                                                 TraceRec *__restrict__ trace, const uint8_t *__restrict__ skip = nullptr)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (regs[b * 4].rows == 0) return;  // leaf reached earlier
+    if (skip && skip[b]) return;        // decided from the histograms (k_q_decide)
     // [4 quadrants][2 passes][kSumPiece * 3]: the chunk sums come through fixed-size pieces (coalesced loads), so the launch's
     // LDS does not grow with the frame
     __shared__ float cs_l[8][kSumPiece * 3];
@@ -441,19 +686,7 @@ __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Regio
         t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
         for (int q = 0; q < 4; ++q) t.score[q] = score[q];
     }
-    const Region k = regs[b * 4 + arg];
-    blk[b] = k;
-    const bool leaf = k.rows <= min_size || k.cols <= min_size;  // six_stadigy.py:76
-    const int mr = k.rows / 2, mc = k.cols / 2;                 // six_stadigy.py:85-86
-    Region q[4] = {{b, k.y0, k.x0, mr, mc},
-                   {b, k.y0, k.x0 + mc, mr, k.cols - mc},
-                   {b, k.y0 + mr, k.x0, k.rows - mr, mc},
-                   {b, k.y0 + mr, k.x0 + mc, k.rows - mr, k.cols - mc}};
-    for (int i = 0; i < 4; ++i) {
-        if (leaf) q[i].rows = q[i].cols = 0;
-        regs[b * 4 + i] = q[i];
-        edges[b * 4 + i] = 0;
-    }
+    q_descend(blk, regs, edges, b, arg, min_size);
 }
 
 // ---- the small levels in one launch ---------------------------------------------------------------------------------
@@ -868,6 +1101,8 @@ LevelBufs carve_level(Carver &c, Shape s)
     L.mean = c.take<float>(nreg * 3);
     L.vtot = c.take<float>(nreg * 3);
     L.edges = c.take<uint32_t>(nreg);
+    L.hist = c.take<uint32_t>(nreg * 768);
+    L.skip = c.take<uint8_t>(s.B);
     return L;
 }
 
@@ -935,23 +1170,49 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         const int qr = (rmax + 1) / 2, qc = (cmax + 1) / 2;  // largest quadrant
         if (use_tail && (long long)qr * qc <= kNpChunk) break;  // k_q_tail walks the rest
         const int nch = cdiv((long long)qr * qc, kNpChunk);
-        // sums -> squared deviations (means derived in the kernel) -> Canny -> select (totals derived in the kernel)
+        // Round 3: byte histograms of the quadrants (+ the gray plane on level 0) -> Canny -> decide from the score
+        // intervals; the exact kernels below return at once for every decided image.  tuning q_hist = 0: exact only.
+        const bool use_hist = tune().q_hist != 0;
+        if (use_hist) {
+            UWIE_HIP_CHECK(hipMemsetAsync(L.hist, 0, sizeof(uint32_t) * (size_t)nreg * 768, st));
+            // ~64 K pixels per block, at least ~2048 blocks when the job has them
+            int nblk = std::max(1, cdiv((long long)qr * qc, 65536));
+            while (nblk * 2 <= qr && (long long)nblk * nreg < 2048 && (long long)qr * qc / (nblk * 2) >= 8192) nblk *= 2;
+            nblk = std::min(nblk, qr);
+            if (gray_pending) {
+                UWIE_LAUNCH(k_q_hist<true>, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist, d_gray,
+                            make_gray_shift);
+                gray_pending = false;
+            } else {
+                UWIE_LAUNCH(k_q_hist<false>, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist,
+                            (uint8_t *)nullptr, 15);
+            }
+            UWIE_LAUNCH_CHECK();
+            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
+            if (rc != UWIE_OK) return rc;
+            UWIE_LAUNCH(k_q_decide, dim3(B), dim3(64), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
+                        (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip);
+            UWIE_LAUNCH_CHECK();
+        }
+        const uint8_t *skip = use_hist ? L.skip : nullptr;
         if (gray_pending) {  // level 0: its four quadrants are the whole frame
             UWIE_LAUNCH((k_q_chunk_sums<false, true>), dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H, s.W,
                         maxChunks, L.csum, (const float *)nullptr, d_gray, make_gray_shift);
             gray_pending = false;
         } else {
             UWIE_LAUNCH(k_q_chunk_sums<false>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H, s.W,
-                        maxChunks, L.csum, (const float *)nullptr, (uint8_t *)nullptr, 15);
+                        maxChunks, L.csum, (const float *)nullptr, (uint8_t *)nullptr, 15, skip);
         }
         UWIE_LAUNCH_CHECK();
         UWIE_LAUNCH(k_q_chunk_sums<true>, dim3(nch, nreg), dim3(64), 0, st, d_in, d_kind, L.regs, L.mean, s.H,
-                           s.W, maxChunks, L.csum_var, (const float *)L.csum, (uint8_t *)nullptr, 15);
+                           s.W, maxChunks, L.csum_var, (const float *)L.csum, (uint8_t *)nullptr, 15, skip);
         UWIE_LAUNCH_CHECK();
-        int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
-        if (rc != UWIE_OK) return rc;
+        if (!use_hist) {
+            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
+            if (rc != UWIE_OK) return rc;
+        }
         UWIE_LAUNCH(k_q_select, dim3(B), dim3(64), 0, st, L.blk, L.regs, (const float *)L.csum, (const float *)L.csum_var,
-                           maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace);
+                           maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace, skip);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
         cmax = qc;

@@ -89,7 +89,7 @@ class Device:
     # ------------------------------------------------------------------ route selectors (uwie_set_tuning)
     def tune(self, **selectors):
         """Set route selectors of this context (include/uwie.h: gf_pipe, gf_split, gf_bands, select_generic, restore_store,
-        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, streams, canny_prepass).  Results are the same bytes on
+        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, q_hist, streams, canny_prepass).  Results are the same bytes on
         every route; tests force the fallback routes with it."""
         for name, value in selectors.items():
             check(self.lib.uwie_set_tuning(self._ctx, name.encode(), int(value)))
