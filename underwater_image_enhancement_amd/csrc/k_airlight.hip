@@ -413,7 +413,8 @@ __device__ void q_descend(Region *__restrict__ blk, Region *__restrict__ regs, u
 constexpr int kQHistCols = 32, kQHistFold = 31;  // fold the 10-bit fields after 31 steps: 31 * 4 pixels * 8 threads per column
 static_assert(kQHistFold * 4 * (256 / kQHistCols) < 1024, "10-bit fields");
 
-template <bool GRAY>
+// NARROW (chosen by the host from the level's largest quadrant): rows of fewer than 256 groups share a step
+template <bool GRAY, bool NARROW>
 __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                 const Region *__restrict__ regs, int H, int W, uint32_t *__restrict__ hist,
                                                 uint8_t *__restrict__ gray_out, int gray_shift)
@@ -457,7 +458,11 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
     auto gray4 = [&](uint32_t rr, uint32_t gg, uint32_t bb) {
         return gray_fixed(t0 ? rr * 17u / 20u : rr, t1 ? gg * 17u / 20u : gg, t2 ? bb * 17u / 20u : bb, gray_shift);
     };
-    const int G = (r.cols + 3) >> 2, trips = (G + 255) >> 8;  // groups of four pixels per row; block-uniform trips per row
+    // groups of four pixels per row: a wide row takes `trips` steps of the block, a narrow one shares a step with RS - 1 more
+    // rows (a 270-column quadrant would otherwise use 68 of 256 threads)
+    const int G = (r.cols + 3) >> 2, trips = (G + 255) >> 8, RS = NARROW ? 256 / G : 1;
+    const int ry = NARROW ? tid / G : 0, gx0 = NARROW ? tid - ry * G : tid;
+    const bool lane_on = ry < RS;
     // A step = one group of four pixels per thread.  The 12 bytes of the NEXT step are loaded (unconditionally, position
     // clamped into the row: see k_chunk_hist) into a second register set before this step's atomics.
     struct Cursor {
@@ -465,18 +470,18 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
     };
     const bool wide = r.cols >= 4;  // (uniform)
     auto advance = [&](Cursor &c) {
-        if (++c.t == trips) { c.t = 0; ++c.y; }
+        if (++c.t == trips) { c.t = 0; c.y += RS; }
     };
     auto fetch = [&](const Cursor &c, uint32_t (&d)[3]) {
         if (!wide) return;
-        const int x = min(4 * (c.t * 256 + tid), r.cols - 4), y = min(c.y, y_hi - 1);
+        const int x = min(4 * (c.t * 256 + gx0), r.cols - 4), y = min(NARROW ? c.y + ry : c.y, y_hi - 1);
         const u32_unaligned *q = reinterpret_cast<const u32_unaligned *>(img + ((size_t)(r.y0 + y) * W + r.x0 + x) * 3);
         d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
     };
     int steps = 0;
     auto body = [&](const Cursor &c, const uint32_t (&d)[3]) {
         if (c.y >= y_hi) return;  // (uniform)
-        const int x = 4 * (c.t * 256 + tid), n = min(4, r.cols - x);
+        const int x = 4 * (c.t * 256 + gx0), yy = NARROW ? c.y + ry : c.y, n = (!NARROW || (lane_on && yy < y_hi)) ? min(4, r.cols - x) : 0;
         if (n == 4) {
             const uint32_t c0 = d[0], c1 = d[1], c2 = d[2];
             // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
@@ -489,14 +494,14 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
                                     gray4(c0 >> 24, c1 & 255, (c1 >> 8) & 255) << 8 |
                                     gray4((c1 >> 16) & 255, c1 >> 24, c2 & 255) << 16 |
                                     gray4((c2 >> 8) & 255, (c2 >> 16) & 255, c2 >> 24) << 24;
-                *reinterpret_cast<u32_unaligned *>(gray + (size_t)(r.y0 + c.y) * W + r.x0 + x) = g4;
+                *reinterpret_cast<u32_unaligned *>(gray + (size_t)(r.y0 + yy) * W + r.x0 + x) = g4;
             }
         } else {
-            const uint8_t *row = img + ((size_t)(r.y0 + c.y) * W + r.x0) * 3;
+            const uint8_t *row = img + ((size_t)(r.y0 + yy) * W + r.x0) * 3;
             for (int j = 0; j < n; ++j) {
                 const uint8_t *p = row + (size_t)(x + j) * 3;
                 bump((uint32_t)p[0] << 7, kR); bump((uint32_t)p[1] << 7, kG); bump((uint32_t)p[2] << 7, kB);
-                if constexpr (GRAY) gray[(size_t)(r.y0 + c.y) * W + r.x0 + x + j] = (uint8_t)gray4(p[0], p[1], p[2]);
+                if constexpr (GRAY) gray[(size_t)(r.y0 + yy) * W + r.x0 + x + j] = (uint8_t)gray4(p[0], p[1], p[2]);
             }
         }
         if (++steps == kQHistFold) {  // (block-uniform)
@@ -543,57 +548,68 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
         if (cnt[i]) atomicAdd(&hist[(size_t)reg * 768 + i], cnt[i]);
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// One wavefront per image: the four quadrants' score intervals from their histograms; decides the level when it can.
+// One workgroup of four wavefronts per image, one per quadrant: the quadrant's score interval from its histogram (the three
+// channels' sums reduced side by side); thread 0 then decides the level when it can.
 // force_exact: leave every image to the exact kernels (the caller records the scores, or tuning q_hist = 2).
-__global__ void __launch_bounds__(64) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
-                                                 const uint32_t *__restrict__ hist, uint32_t *__restrict__ edges,
-                                                 const int32_t *__restrict__ kind, int min_size, int force_exact,
-                                                 uint8_t *__restrict__ skip)
+__global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
+                                                  const uint32_t *__restrict__ hist, uint32_t *__restrict__ edges,
+                                                  const int32_t *__restrict__ kind, int min_size, int force_exact,
+                                                  uint8_t *__restrict__ skip)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_lo[4], s_hi[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     if (regs[b * 4].rows == 0) {  // leaf reached earlier: nothing left to decide
-        if (lane == 0) skip[b] = 1;
+        if (threadIdx.x == 0) skip[b] = 1;
         return;
     }
     if (force_exact) {
-        if (lane == 0) skip[b] = 0;
+        if (threadIdx.x == 0) skip[b] = 0;
         return;
     }
     const int knd = kind ? kind[b] : 0;
     constexpr double u = 0x1p-24, kSafe = 1.25;
-    double qlo[4], qhi[4], qmid[4];
-    for (int q = 0; q < 4; ++q) {
+    {
         const Region r = regs[b * 4 + q];
         const double n = (double)r.rows * (double)r.cols;
         const int nch = (int)(((long long)r.rows * r.cols + kNpChunk - 1) / kNpChunk);
         const double eS = kSafe * (nch + 35) * u, eV = kSafe * (nch + 38) * u;
-        double Slo[3], Shi[3], Vlo[3], Vhi[3];
+        double xs[3][4], ns[3][4], S[3], V[3];
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t *hc = hist + ((size_t)(b * 4 + q) * 3 + c) * 256;
             const float a = px_atten(knd, c) ? 0.85f : 1.0f;
-            double xs[4], ns[4], part = 0.0;
+            S[c] = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int v = lane + 64 * k;
-                xs[k] = (double)(px_norm_fast((uint32_t)v) * a);  // the element's float32 value, exactly as the sums see it
-                ns[k] = (double)hc[v];
-                part += ns[k] * xs[k];
+                xs[c][k] = (double)(px_norm_fast((uint32_t)v) * a);  // the element's float32 value, exactly as the sums see it
+                ns[c][k] = (double)hc[v];
+                S[c] += ns[c][k] * xs[c][k];
             }
-            const double S = wave_sum_f64(part), m = S / n;
-            part = 0.0;
+        }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part += ns[k] * (xs[k] - m) * (xs[k] - m);
-            const double V = wave_sum_f64(part);
-            const double dm = (eS + 2 * u) * fabs(m);  // |m~ - m|: the rounded sum, its division, its conversion to float32
-            Slo[c] = S * (1.0 - eS); Shi[c] = S * (1.0 + eS);
-            Vlo[c] = V * (1.0 - eV); Vhi[c] = (V + n * dm * dm) * (1.0 + eV);
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[c] += __shfl_xor(S[c], o);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double m = S[c] / n;
+            V[c] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) V[c] += ns[c][k] * (xs[c][k] - m) * (xs[c][k] - m);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) V[c] += __shfl_xor(V[c], o);
+        }
+        double Slo[3], Shi[3], Vlo[3], Vhi[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double dm = (eS + 2 * u) * fabs(S[c] / n);  // |m~ - m|: the rounded sum, its division, its conversion to float32
+            Slo[c] = S[c] * (1.0 - eS); Shi[c] = S[c] * (1.0 + eS);
+            Vlo[c] = V[c] * (1.0 - eV); Vhi[c] = (V[c] + n * dm * dm) * (1.0 + eV);
         }
         // six_stadigy.py:134-155 in float32: every operation rounds once (u), conversions of n included
         const double sA = fabs(Shi[0]) + fabs(Shi[1]) + fabs(Shi[2]);
@@ -603,17 +619,19 @@ __global__ void __launch_bounds__(64) k_q_decide(Region *__restrict__ blk, Regio
         const double t4 = (double)edges[b * 4 + q] / n;
         // rounding of the float32 expression tree: <= 6 operations on terms bounded by these magnitudes
         const double slack = kSafe * 8.0 * u * (sA / (3.0 * n) + (fabs(Shi[2]) + fabs(Shi[1]) + 2.0 * fabs(Shi[0])) / n + fabs(t3hi)) + 1e-300;
-        qlo[q] = (t1lo + t2lo) - t3hi - t4 - slack;
-        qhi[q] = (t1hi + t2hi) - t3lo - t4 + slack;
-        qmid[q] = 0.5 * (qlo[q] + qhi[q]);
+        if (lane == 0) {
+            s_lo[q] = (t1lo + t2lo) - t3hi - t4 - slack;
+            s_hi[q] = (t1hi + t2hi) - t3lo - t4 + slack;
+        }
     }
-    if (lane != 0) return;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int arg = 0;
-    for (int q = 1; q < 4; ++q)
-        if (qmid[q] > qmid[arg]) arg = q;
+    for (int i = 1; i < 4; ++i)
+        if (s_lo[i] + s_hi[i] > s_lo[arg] + s_hi[arg]) arg = i;
     bool sure = true;
-    for (int q = 0; q < 4; ++q)
-        if (q != arg && !(qlo[arg] > qhi[q])) sure = false;
+    for (int i = 0; i < 4; ++i)
+        if (i != arg && !(s_lo[arg] > s_hi[i])) sure = false;
     skip[b] = sure ? 1 : 0;
     if (sure) q_descend(blk, regs, edges, b, arg, min_size);
 }
@@ -1179,18 +1197,29 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
             int nblk = std::max(1, cdiv((long long)qr * qc, 65536));
             while (nblk * 2 <= qr && (long long)nblk * nreg < 2048 && (long long)qr * qc / (nblk * 2) >= 8192) nblk *= 2;
             nblk = std::min(nblk, qr);
+            // (rows of fewer than 256 four-pixel groups: several rows per step; every quadrant of the level is at most qc wide)
+            const bool narrow = cdiv(qc, 4) < 256;
+            const auto k_q_hist_gray = k_q_hist<true, false>, k_q_hist_gray_narrow = k_q_hist<true, true>;
+            const auto k_q_hist_wide = k_q_hist<false, false>, k_q_hist_narrow = k_q_hist<false, true>;
             if (gray_pending) {
-                UWIE_LAUNCH(k_q_hist<true>, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist, d_gray,
-                            make_gray_shift);
+                if (narrow)
+                    UWIE_LAUNCH(k_q_hist_gray_narrow, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist, d_gray,
+                                make_gray_shift);
+                else
+                    UWIE_LAUNCH(k_q_hist_gray, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist, d_gray,
+                                make_gray_shift);
                 gray_pending = false;
+            } else if (narrow) {
+                UWIE_LAUNCH(k_q_hist_narrow, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist,
+                            (uint8_t *)nullptr, 15);
             } else {
-                UWIE_LAUNCH(k_q_hist<false>, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist,
+                UWIE_LAUNCH(k_q_hist_wide, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist,
                             (uint8_t *)nullptr, 15);
             }
             UWIE_LAUNCH_CHECK();
             int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
             if (rc != UWIE_OK) return rc;
-            UWIE_LAUNCH(k_q_decide, dim3(B), dim3(64), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
+            UWIE_LAUNCH(k_q_decide, dim3(B), dim3(256), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
                         (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip);
             UWIE_LAUNCH_CHECK();
         }
