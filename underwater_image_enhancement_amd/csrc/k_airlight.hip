@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
 // channels' sums reduced side by side); thread 0 then decides the level when it can.
 // force_exact: leave every image to the exact kernels (the caller records the scores, or tuning q_hist = 2).
 __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
-                                                  const uint32_t *__restrict__ hist, uint32_t *__restrict__ edges,
+                                                  const uint32_t *hist, uint32_t *__restrict__ edges,
                                                   const int32_t *__restrict__ kind, int min_size, int force_exact,
                                                   uint8_t *__restrict__ skip)
 {
@@ -562,8 +562,14 @@ __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Regi
         if (threadIdx.x == 0) skip[b] = 1;
         return;
     }
+    // every exit below leaves the image's four histograms zeroed for the next level (one memset per call, not per level)
+    uint32_t *hq = const_cast<uint32_t *>(hist) + (size_t)(b * 4 + q) * 768;
+    auto clear = [&]() {
+        for (int i = lane; i < 768; i += 64) hq[i] = 0;
+    };
     if (force_exact) {
         if (threadIdx.x == 0) skip[b] = 0;
+        clear();
         return;
     }
     const int knd = kind ? kind[b] : 0;
@@ -623,6 +629,7 @@ __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Regi
             s_lo[q] = (t1lo + t2lo) - t3hi - t4 - slack;
             s_hi[q] = (t1hi + t2hi) - t3lo - t4 + slack;
         }
+        clear();  // (this wavefront's own reads of hq are done: the values sit in ns[][])
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -1192,7 +1199,7 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         // intervals; the exact kernels below return at once for every decided image.  tuning q_hist = 0: exact only.
         const bool use_hist = tune().q_hist != 0;
         if (use_hist) {
-            UWIE_HIP_CHECK(hipMemsetAsync(L.hist, 0, sizeof(uint32_t) * (size_t)nreg * 768, st));
+            if (level == 0) UWIE_HIP_CHECK(hipMemsetAsync(L.hist, 0, sizeof(uint32_t) * (size_t)nreg * 768, st));  // (k_q_decide clears after use)
             // ~64 K pixels per block, at least ~2048 blocks when the job has them
             int nblk = std::max(1, cdiv((long long)qr * qc, 65536));
             while (nblk * 2 <= qr && (long long)nblk * nreg < 2048 && (long long)qr * qc / (nblk * 2) >= 8192) nblk *= 2;
