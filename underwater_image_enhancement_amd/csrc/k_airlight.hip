@@ -963,12 +963,20 @@ __device__ uint32_t tail_hysteresis(uint16_t *st, int rows, int cols, int lane)
 __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                            const uint8_t *__restrict__ gray, Region *__restrict__ blk, int H,
                                                            int W, int level0, int min_size, TraceRec *__restrict__ trace,
-                                                           float *__restrict__ A)
+                                                           float *__restrict__ A, int use_hist)
 {
+#ifdef UWIE_TAIL_PROF
+    const bool hist_mode = use_hist;  // (profiling build: the trace carries phase times, not scores)
+#else
+    const bool hist_mode = use_hist && !trace;  // (recorded scores are the exact ones)
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t tail_lds[];
     __shared__ double s_q[4];
     __shared__ float s_sum[4][3];
     __shared__ int s_strong[4], s_nlev[4];
+    __shared__ uint32_t s_edges[4];
+    __shared__ double s_ilo[4], s_ihi[4], s_sv[4][6];
+    __shared__ int s_dec;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qd = wid / kTailSub, sw = wid % kTailSub, ql = sw * 64 + lane;  // quadrant, wavefront and lane inside it
     uint8_t *pix = tail_lds + (size_t)qd * kTailQuadBytes;
@@ -991,54 +999,90 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
         const uint64_t c0 = wall_clock64();
         const uint64_t k0 = clock64();
 #endif
-        // compute_Q (six_stadigy.py:116-157): sums, means, squared deviations
-        int nlev = 0;
-        if (sw == 0) {
-            nlev = pairwise_build<float, 128, 8, true>(n, lane, tree);
-            if (lane == 0) s_nlev[qd] = nlev;
-        }
+        // Round 3: the level is decided from the quadrants' byte histograms when the score intervals separate (see
+        // k_q_decide: same sums, same bounds, nch = 1); the NumPy-order sums below only run otherwise, or when the scores
+        // themselves are recorded.  The histogram borrows the tree's LDS (the tree is only built for the exact sums).
+        uint32_t *hq = reinterpret_cast<uint32_t *>(&tree);
+        static_assert(sizeof(TailTree) >= 768 * sizeof(uint32_t), "the quadrant's histogram fits the tree's space");
         if (threadIdx.x < 4) s_strong[threadIdx.x] = 0;
         tail_stage(img + ((size_t)r.y0 * W + r.x0) * 3, (size_t)W * 3, r.rows, r.cols * 3, pix, ql, 64 * kTailSub);
-        __syncthreads();
-#ifdef UWIE_TAIL_PROF
-        const uint64_t ca = wall_clock64();
-#endif
-        nlev = s_nlev[qd];
-        float S[3], V[3];
-        {
-            Elem<false> el;
-            el.img = nullptr; el.W = 0; el.set_kind(knd);
-            tail_leaves<false>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
-        }
-        __syncthreads();
-#ifdef UWIE_TAIL_PROF
-        const uint64_t cb = wall_clock64();
-#endif
-        if (sw == 0) {
-            pairwise_combine<float, 128, 8, true>(nlev, lane, tree, S);
-            if (lane < 3) s_sum[qd][lane] = S[lane];
-        }
-        __syncthreads();
-#ifdef UWIE_TAIL_PROF
-        const uint64_t cc = wall_clock64();
-#endif
-        {
-            Elem<true> el;
-            el.img = nullptr; el.W = 0; el.set_kind(knd);
+        if (hist_mode) {
+            for (int i = ql; i < 768; i += 64 * kTailSub) hq[i] = 0;
+            __syncthreads();
+            {   // a lane counts runs of equal bytes in registers: a flat quadrant would otherwise put every one of its pixels on
+                // three LDS addresses (same-address atomics serialise).  Its pixels are 256 apart, so that neighbouring lanes
+                // read neighbouring bytes (consecutive pixels per lane: 96-byte lane stride, 16-way bank conflicts)
+                uint32_t cur[3] = {0, 0, 0}, run[3] = {0, 0, 0};
+                for (int e = ql; e < n; e += 64 * kTailSub) {
+                    const uint8_t *p = pix + (size_t)e * 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                S[c] = s_sum[qd][c];
-                el.mean[c] = (float)((double)S[c] / (double)n);  // numpy/_core/_methods.py:_mean
+                    for (int c = 0; c < 3; ++c) {
+                        const uint32_t v = p[c];
+                        if (v != cur[c]) {
+                            if (run[c]) atomicAdd(&hq[c * 256 + cur[c]], run[c]);
+                            cur[c] = v;
+                            run[c] = 0;
+                        }
+                        ++run[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (run[c]) atomicAdd(&hq[c * 256 + cur[c]], run[c]);
             }
-            tail_leaves<true>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
+            __syncthreads();
+            // the score interval without the edge term (added once the Canny count is known): wavefronts 0 .. 2 of the
+            // quadrant take one channel's sums each, lane 0 of wavefront 0 the bounds
+            constexpr double u = 0x1p-24, kSafe = 1.25;
+            const double nd = (double)n;
+            if (sw < 3) {
+                const int c = sw;
+                const float a = px_atten(knd, c) ? 0.85f : 1.0f;
+                double xs[4], ns[4], acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = lane + 64 * j;
+                    xs[j] = (double)(px_norm_fast((uint32_t)v) * a);
+                    ns[j] = (double)hq[c * 256 + v];
+                    acc += ns[j] * xs[j];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                const double Sc = acc, m = acc / nd;
+                acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += ns[j] * (xs[j] - m) * (xs[j] - m);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                if (lane == 0) {
+                    s_sv[qd][c] = Sc;
+                    s_sv[qd][3 + c] = acc;
+                }
+            }
+            __syncthreads();
+            if (sw == 0 && lane == 0) {
+                const double eS = kSafe * 36.0 * u, eV = kSafe * 39.0 * u;
+                double Slo[3], Shi[3], Vlo[3], Vhi[3];
+                for (int c = 0; c < 3; ++c) {
+                    const double Sc = s_sv[qd][c], Vc = s_sv[qd][3 + c];
+                    const double dm = (eS + 2 * u) * fabs(Sc / nd);
+                    Slo[c] = Sc * (1.0 - eS); Shi[c] = Sc * (1.0 + eS);
+                    Vlo[c] = Vc * (1.0 - eV); Vhi[c] = (Vc + nd * dm * dm) * (1.0 + eV);
+                }
+                const double t1lo = (Slo[0] + Slo[1] + Slo[2]) / (3.0 * nd), t1hi = (Shi[0] + Shi[1] + Shi[2]) / (3.0 * nd);
+                const double t2lo = (Slo[2] + Slo[1] - 2.0 * Shi[0]) / nd, t2hi = (Shi[2] + Shi[1] - 2.0 * Slo[0]) / nd;
+                const double t3lo = (Vlo[0] + Vlo[1] + Vlo[2]) / (3.0 * nd), t3hi = (Vhi[0] + Vhi[1] + Vhi[2]) / (3.0 * nd);
+                const double slack = kSafe * 8.0 * u * ((Shi[0] + Shi[1] + Shi[2]) / (3.0 * nd) + (Shi[2] + Shi[1] + 2.0 * Shi[0]) / nd + t3hi) + 1e-300;
+                s_ilo[qd] = (t1lo + t2lo) - t3hi - slack;
+                s_ihi[qd] = (t1hi + t2hi) - t3lo + slack;
+            }
         }
         __syncthreads();
 #ifdef UWIE_TAIL_PROF
         const uint64_t c1 = wall_clock64();
 #endif
-        // the RGB bytes are done with: gray comes in while one wavefront folds the squared deviations
-        if (sw == 0) pairwise_combine<float, 128, 8, true>(nlev, lane, tree, V);
-        else tail_stage(g + (size_t)r.y0 * W + r.x0, (size_t)W, r.rows, r.cols, sg, ql - 64, 64 * (kTailSub - 1));
+        // the RGB bytes are done with (for now): gray comes in
+        tail_stage(g + (size_t)r.y0 * W + r.x0, (size_t)W, r.rows, r.cols, sg, ql, 64 * kTailSub);
         __syncthreads();
 #ifdef UWIE_TAIL_PROF
         const uint64_t c2 = wall_clock64();
@@ -1051,36 +1095,96 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
         __syncthreads();
         if (sw == 0) {
             const uint32_t edges = s_strong[qd] ? tail_hysteresis(st, r.rows, r.cols, lane) : 0u;  // no strong pixel: no edge
-            if (lane == 0) {
-                const float t1 = ((S[0] + S[1]) + S[2]) / (float)(3 * (long long)n);
-                const float t2 = ((S[2] + S[1]) - 2.0f * S[0]) / (float)n;
-                const float v0 = V[0] / (float)n, v1 = V[1] / (float)n, v2 = V[2] / (float)n;
-                const float t3 = ((v0 + v1) + v2) / 3.0f;
-                const double t4 = (double)edges / (double)n;  // int64 / int -> float64
-                s_q[qd] = (double)((t1 + t2) - t3) - t4;
-            }
+            if (lane == 0) s_edges[qd] = edges;
         }
         __syncthreads();
-#ifdef UWIE_TAIL_PROF
-        const uint64_t c3 = wall_clock64();
-#endif
-        double score[4];
-        for (int q = 0; q < 4; ++q) score[q] = s_q[q];
         int arg = 0;
-        for (int q = 1; q < 4; ++q)
-            if (score[q] > score[arg]) arg = q;  // np.argmax: first maximum
-        if (trace && threadIdx.x == 0) {
-            TraceRec &t = trace[b * kMaxLevels + level];
-            t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
-            for (int q = 0; q < 4; ++q) t.score[q] = score[q];
-#ifdef UWIE_TAIL_PROF  // 100 MHz ticks: sums, gray load, Canny
-            t.score[0] = (double)(c1 - c0); t.score[1] = (double)(c2 - c1); t.score[2] = (double)(c3 - c2);
-            t.score[3] = (double)(clock64() - k0) / (double)(wall_clock64() - c0);  // shader clocks per 10 ns
-#ifdef UWIE_TAIL_PROF2  // the sums phase in detail: build + stage, leaves, combine, squared-deviation leaves
-            t.score[0] = (double)(ca - c0); t.score[1] = (double)(cb - ca); t.score[2] = (double)(cc - cb); t.score[3] = (double)(c1 - cc);
-#endif
-#endif
+        bool sure = false;
+        if (hist_mode) {
+            if (threadIdx.x == 0) {  // one thread decides (its doubles would cost every lane registers), everybody reads
+                double lo[4], hi[4];
+                const int rows4[4] = {mr, mr, k.rows - mr, k.rows - mr}, cols4[4] = {mc, k.cols - mc, mc, k.cols - mc};
+                for (int q = 0; q < 4; ++q) {
+                    const double t4 = (double)s_edges[q] / ((double)rows4[q] * (double)cols4[q]);
+                    lo[q] = s_ilo[q] - t4;
+                    hi[q] = s_ihi[q] - t4;
+                }
+                int best = 0;
+                for (int q = 1; q < 4; ++q)
+                    if (lo[q] + hi[q] > lo[best] + hi[best]) best = q;
+                bool ok = true;
+                for (int q = 0; q < 4; ++q)
+                    if (q != best && !(lo[best] > hi[q])) ok = false;
+                s_dec = best | (ok ? 256 : 0);
+            }
+            __syncthreads();
+            arg = s_dec & 255;
+            sure = (s_dec >> 8) != 0;
         }
+        if (!sure) {  // (workgroup-uniform) the exact NumPy-order sums: the RGB bytes come in again
+            __syncthreads();
+            int nlev = 0;
+            if (sw == 0) {
+                nlev = pairwise_build<float, 128, 8, true>(n, lane, tree);
+                if (lane == 0) s_nlev[qd] = nlev;
+            }
+            tail_stage(img + ((size_t)r.y0 * W + r.x0) * 3, (size_t)W * 3, r.rows, r.cols * 3, pix, ql, 64 * kTailSub);
+            __syncthreads();
+            nlev = s_nlev[qd];
+            float S[3], V[3];
+            {
+                Elem<false> el;
+                el.img = nullptr; el.W = 0; el.set_kind(knd);
+                tail_leaves<false>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
+            }
+            __syncthreads();
+            if (sw == 0) {
+                pairwise_combine<float, 128, 8, true>(nlev, lane, tree, S);
+                if (lane < 3) s_sum[qd][lane] = S[lane];
+            }
+            __syncthreads();
+            {
+                Elem<true> el;
+                el.img = nullptr; el.W = 0; el.set_kind(knd);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    S[c] = s_sum[qd][c];
+                    el.mean[c] = (float)((double)S[c] / (double)n);  // numpy/_core/_methods.py:_mean
+                }
+                tail_leaves<true>(el, pix, tree, nlev, ql >> 3, 8 * kTailSub, lane & 7);
+            }
+            __syncthreads();
+            if (sw == 0) {
+                pairwise_combine<float, 128, 8, true>(nlev, lane, tree, V);
+                if (lane == 0) {
+                    const float t1 = ((S[0] + S[1]) + S[2]) / (float)(3 * (long long)n);
+                    const float t2 = ((S[2] + S[1]) - 2.0f * S[0]) / (float)n;
+                    const float v0 = V[0] / (float)n, v1 = V[1] / (float)n, v2 = V[2] / (float)n;
+                    const float t3 = ((v0 + v1) + v2) / 3.0f;
+                    const double t4 = (double)s_edges[qd] / (double)n;  // int64 / int -> float64
+                    s_q[qd] = (double)((t1 + t2) - t3) - t4;
+                }
+            }
+            __syncthreads();
+            double score[4];
+            for (int q = 0; q < 4; ++q) score[q] = s_q[q];
+            arg = 0;
+            for (int q = 1; q < 4; ++q)
+                if (score[q] > score[arg]) arg = q;  // np.argmax: first maximum
+            if (trace && threadIdx.x == 0) {
+                TraceRec &t = trace[b * kMaxLevels + level];
+                t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
+                for (int q = 0; q < 4; ++q) t.score[q] = score[q];
+            }
+        }
+#ifdef UWIE_TAIL_PROF
+        if (trace && threadIdx.x == 0) {  // 100 MHz ticks: staging + histogram, gray load, Canny + decision
+            TraceRec &t = trace[b * kMaxLevels + level];
+            const uint64_t c3 = wall_clock64();
+            t.score[0] = (double)(c1 - c0); t.score[1] = (double)(c2 - c1); t.score[2] = (double)(c3 - c2);
+            t.score[3] = (double)(clock64() - k0) / (double)(c3 - c0);
+        }
+#endif
         k = arg == 0   ? Region{b, k.y0, k.x0, mr, mc}
             : arg == 1 ? Region{b, k.y0, k.x0 + mc, mr, k.cols - mc}
             : arg == 2 ? Region{b, k.y0 + mr, k.x0, k.rows - mr, mc}
@@ -1263,7 +1367,7 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         }
     }
     UWIE_LAUNCH(k_q_tail, dim3(B), dim3(256 * kTailSub), 4 * kTailQuadBytes, st, d_in, d_kind, d_gray, L.blk, s.H, s.W, level, min_size,
-                (TraceRec *)d_trace, d_A);
+                (TraceRec *)d_trace, d_A, tune().q_hist == 1 ? 1 : 0);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
