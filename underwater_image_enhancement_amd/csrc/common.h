@@ -176,7 +176,9 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
 // k_canny.hip  (regions: device array of nreg Region; max_rows/max_cols bound every region)
 size_t canny_ws_bytes(Shape s);
 int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
-                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed = false);
+                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed = false,
+                 bool strong_is_zeroed = false);
+uint32_t *canny_strong_flags(void *ws, Shape s);  // the pre-pass flags inside a Canny workspace ([regions])
 int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st);
 
 // k_airlight.hip: NumPy-order sum / mean / sum of squared deviations per region and channel

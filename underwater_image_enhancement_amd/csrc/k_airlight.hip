@@ -554,10 +554,11 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
 __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
                                                   const uint32_t *hist, uint32_t *__restrict__ edges,
                                                   const int32_t *__restrict__ kind, int min_size, int force_exact,
-                                                  uint8_t *__restrict__ skip)
+                                                  uint8_t *__restrict__ skip, uint32_t *__restrict__ strong)
 {
     __shared__ double s_lo[4], s_hi[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (lane == 0) strong[b * 4 + q] = 0;  // the Canny pre-pass flags of this level are consumed: clean for the next one
     if (regs[b * 4].rows == 0) {  // leaf reached earlier: nothing left to decide
         if (threadIdx.x == 0) skip[b] = 1;
         return;
@@ -1328,10 +1329,10 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
                             (uint8_t *)nullptr, 15);
             }
             UWIE_LAUNCH_CHECK();
-            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true);
+            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0);
             if (rc != UWIE_OK) return rc;
             UWIE_LAUNCH(k_q_decide, dim3(B), dim3(256), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
-                        (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip);
+                        (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip, canny_strong_flags(canny_ws, s));
             UWIE_LAUNCH_CHECK();
         }
         const uint8_t *skip = use_hist ? L.skip : nullptr;

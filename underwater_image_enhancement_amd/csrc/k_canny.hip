@@ -727,8 +727,15 @@ int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st)
     return UWIE_OK;
 }
 
+uint32_t *canny_strong_flags(void *ws, Shape s)
+{
+    Carver c(ws);
+    return carve_canny(c, s).strong;
+}
+
 int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
-                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed)
+                 int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed,
+                 bool strong_is_zeroed)
 {
     Carver c(ws);
     CannyBufs bufs = carve_canny(c, s);
@@ -748,7 +755,7 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     // threshold have no edges.  Tuning canny_prepass = 0 disables it.
     if (d_edges || nreg > s.B * 4 || !tune().canny_prepass) bufs.strong = nullptr;
     if (bufs.strong) {
-        UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
+        if (!strong_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
         if (max_cols >= 8) {  // the streaming pre-pass loads 8 bytes per row
             const int strips = cdiv(max_cols, kPreCols), bandgroups = cdiv(cdiv(max_rows, kPreRows), 4);
             UWIE_LAUNCH(k_canny_strong, dim3(strips * bandgroups, nreg), block, 0, st, d_gray, d_regions, s.H, s.W, strips, high,
