@@ -34,6 +34,7 @@ extern "C" {
 #define UWIE_E_WORKSPACE (-2) /* workspace too small */
 #define UWIE_E_HIP (-3)       /* a HIP runtime call failed */
 #define UWIE_E_NODEVICE (-4)  /* no gfx950 device / code object cannot load */
+#define UWIE_E_DEVICE (-5)    /* a kernel found one of its own invariants violated (uwie_device_status) */
 
 /* which reference surface's arithmetic to follow */
 #define UWIE_SURFACE_SIX 0  /* six_stadigy.EnhancementStrategies.strategy1..6 (S6:230-285)        */
@@ -102,6 +103,17 @@ const char *uwie_version(void);
 
 int uwie_create(int device, uwie_ctx **out_ctx);
 void uwie_destroy(uwie_ctx *ctx);
+
+/* Device-side self checks (no reference counterpart).  Kernels that chase indices through workspace memory validate every
+ * index before dereferencing it; one that is out of range is not followed -- the kernel sets a bit in the context's
+ * device status word and carries on with a safe substitute, so a defect in the library is an error code, never a memory
+ * access fault.  Entry points do not synchronise, so they cannot report it themselves: uwie_device_status waits for
+ * `stream`, returns UWIE_OK when no bit is set and UWIE_E_DEVICE otherwise (*bits, optional, receives the word; the word
+ * is cleared).  A caller that reads results back synchronises anyway and calls this right after (the Python wrapper does).
+ *   UWIE_STATUS_CANNY_LABEL  cv2.Canny's hysteresis (S6:150; k_canny.hip union / mark / emit / paint) met a component
+ *                            label that the current launch did not write. */
+#define UWIE_STATUS_CANNY_LABEL 1u
+int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits);
 
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference only has a per-image wall clock,
  * S6:393-500).  enable(1) starts recording one HIP-event pair per kernel launch on the launch stream;

@@ -137,12 +137,50 @@ def test_process_batch_log_rows_match_the_driver_columns():
     outs, rows, stats = uw.process_batch(frames, ["x.jpg", "y.jpg"], compute=fake)
     assert [r["strategy"] for r in rows[:6]] == ["strong_dehazing", "medium_dehazing", "light_dehazing",
                                                   "clahe_enhancement", "white_balance", "histogram_eq"]
-    assert set(rows[0]) == {"filename", "image_type", "strategy", "strategy_desc", "status", "processing_time"}
+    assert set(rows[0]) == {"filename", "image_type", "strategy", "strategy_desc", "status", "output_path", "processing_time"}
     assert rows[0]["image_type"] == "greenish" and rows[6]["filename"] == "y.jpg" and rows[6]["image_type"] == "normal"
     assert stats["image_types"] == {"greenish": 1, "bluish": 0, "normal": 1} and stats["successful_outputs"] == 12
     assert stats["processed_images"] == 2 and stats["total_images"] == 2
     with pytest.raises(ValueError):
         uw.process_batch(frames, ["only-one"], compute=fake)
+
+
+def test_process_batch_failed_rows_follow_the_drivers_two_try_levels():
+    """six_stadigy.py:424-480: a strategy that raises is a row with status 'failed', 'Error: <50 chars>' and 'N/A', counted in
+    failed_outputs, while the image's other strategies still succeed; an image without a single success counts in
+    failed_images (S6:484-488).  Injected computes, no GPU: the fused call fails for the batch and for image 1, whose
+    strategy 3 then fails on its own; image 2 fails in every strategy."""
+    import numpy as np
+
+    frames = np.zeros((3, 4, 5, 3), np.uint8)
+    frames[1] = 1
+    frames[2] = 2
+
+    def fused(f):
+        if len(f) > 1 or f[0, 0, 0, 0] != 0:
+            raise RuntimeError("fused path down")
+        return {n: f.copy() for n, _ in uw.DRIVER_STRATEGIES}, ["bluish"] * len(f)
+
+    def one(f, k):
+        if f[0, 0, 0] == 2 or k == 3:
+            raise RuntimeError("strategy %d broke: " % k + "x" * 80)
+        return f + k
+
+    outs, rows, stats = uw.process_batch(frames, ["a", "b", "c"], compute=fused, compute_one=one)
+    assert len(rows) == 18 and [r["status"] for r in rows[:6]] == ["success"] * 6  # image 0: its own fused call worked
+    b = rows[6:12]
+    assert [r["status"] for r in b] == ["success", "success", "failed", "success", "success", "success"]
+    assert b[2]["processing_time"] == "N/A" and b[2]["output_path"] == "Error: " + ("strategy 3 broke: " + "x" * 80)[:50]
+    assert b[0]["processing_time"].endswith("s") and b[0]["output_path"] == ""
+    assert all(r["status"] == "failed" for r in rows[12:])
+    assert stats["processed_images"] == 2 and stats["failed_images"] == 1 and stats["total_outputs"] == 18
+    assert stats["successful_outputs"] == 11 and stats["failed_outputs"] == 7
+    assert outs["light_dehazing"][1] is None and np.array_equal(outs["medium_dehazing"][1], frames[1] + 2)
+    assert outs["strong_dehazing"][2] is None and np.array_equal(outs["histogram_eq"][0], frames[0])
+    # frames of different sizes run image by image through the fused call
+    ragged = [np.zeros((4, 5, 3), np.uint8), np.zeros((6, 7, 3), np.uint8)]
+    outs, rows, stats = uw.process_batch(ragged, compute=lambda f: ({n: f.copy() for n, _ in uw.DRIVER_STRATEGIES}, ["normal"] * len(f)))
+    assert stats["successful_outputs"] == 12 and outs["white_balance"][1].shape == (6, 7, 3)
 
 
 def test_no_entry_point_reads_the_environment():
@@ -239,3 +277,44 @@ def test_gray_quantisation_identities():
     x = u.astype(np.float32) / np.float32(255.0)
     assert np.array_equal((x * np.float32(255.0)).astype(np.uint8), u)
     assert np.array_equal(((x * np.float32(0.85)) * np.float32(255.0)).astype(np.uint8), u * 17 // 20)
+
+
+def test_no_vgpr_spill_ahead_of_an_exec_restore():
+    """profiles/isa_lint.py over the device assembly the build keeps (lib/obj/*-gfx950.s): the miscompile behind round 3's
+    255-LSB build of k_stretch_lab_lut<1, 256> -- VGPR spill stores at the head of a join block, ahead of the s_or_b64 that
+    restores EXEC, so lanes that sat the branch out lose their threadIdx.x (profiles/r04_spill_miscompile.txt) -- fails the
+    build here instead of on the GPU.  The lint itself is checked on the two excerpts kept from that investigation."""
+    import glob
+    import importlib.util
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(root, "profiles", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = """k_demo:
+	s_and_saveexec_b64 s[22:23], s[0:1]
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	v_mov_b32_e32 v1, v2
+.LBB0_2:
+	scratch_store_dwordx2 off, v[76:77], off offset:12 ; 8-byte Folded Spill
+	s_or_b64 exec, exec, s[22:23]
+	s_endpgm
+"""
+    good = bad.replace("\tscratch_store_dwordx2 off, v[76:77], off offset:12 ; 8-byte Folded Spill\n\ts_or_b64 exec, exec, s[22:23]\n",
+                       "\ts_or_b64 exec, exec, s[22:23]\n\tscratch_store_dwordx2 off, v[76:77], off offset:12 ; 8-byte Folded Spill\n")
+    assert good != bad
+    with tempfile.TemporaryDirectory() as d:
+        for name, text, n in (("bad.s", bad, 1), ("good.s", good, 0)):
+            path = os.path.join(d, name)
+            with open(path, "w") as f:
+                f.write(text)
+            assert len(lint.lint(path)) == n, name
+    files = sorted(glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "obj", "*gfx950.s")))
+    if not files:  # a library built before the Makefile kept the assembly
+        _lib.build(force=True)
+        files = sorted(glob.glob(os.path.join(os.path.dirname(_lib.LIB_PATH), "obj", "*gfx950.s")))
+    assert len(files) >= 17, "the build keeps one device assembly file per .hip source"
+    findings = [f for p in files for f in lint.lint(p)]
+    assert not findings, "\n".join(findings)

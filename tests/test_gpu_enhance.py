@@ -44,6 +44,26 @@ def test_enhance_matches_oracle(uw, orc, strategy):
     assert diff == 0, f"strategy {strategy}: {diff} of {total} bytes differ by 1 LSB"
 
 
+@pytest.mark.parametrize("shape", [(5, 7), (9, 300), (300, 9), (2, 3), (1, 1), (1, 40), (16, 16)])
+def test_frames_smaller_than_the_filter_window_and_the_tile_grid(uw, orc, shape):
+    """frames narrower than the guided filter's window (10 / 15 / 20), than CLAHE's 8 x 8 tile grid and
+    than one quadtree split, end to end on both surfaces against the oracle (which follows the reference: cv2.boxFilter's
+    BORDER_REFLECT_101 of a source shorter than the window, CLAHE's reflected padding up to the tile grid, a quadtree that
+    stops at once).  Bit-identical, gamma strategies within 1 LSB."""
+    rng = np.random.default_rng(1000 + shape[0] * 31 + shape[1])
+    u8 = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    for k in range(1, 7):
+        n = check_u8(uw.enhance(u8, strategy=k), orc.enhance_u8(u8, k), f"strategy {k} on {shape}")
+        assert n == 0 or k in (1, 4, 5, 6), f"strategy {k} on {shape}: {n} bytes differ"
+    x = orc.normalise_u8(u8)
+    for name in ("strong_dehazing", "medium_dehazing", "light_enhancement", "clahe_enhancement", "histogram_equalization"):
+        params = orc.CONFIG_STRATEGIES[name]
+        want = (orc.DictStrategyOracle.run(x, name, params) * 255).astype(np.uint8)
+        got = (uw.EnhancementStrategies.apply_strategy(x, name, params) * 255).astype(np.uint8)
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1, f"{name} on {shape}: {d.max()} LSB"
+
+
 def test_enhance_ragged_midsize(uw, orc):
     """Frames large enough for the launched quadtree levels (level 0 writes the gray plane on the way: GrayOut in
     k_airlight.hip) with sizes that put leaves across row ends and leave ragged chunks: the gray plane feeds the guided

@@ -126,6 +126,17 @@ def test_f32t_transmission_stated_tolerance(uw, orc):
     # the mode is a permission, not an obligation: windows / frames the wavefront kernels do not take keep float64
     odd = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
     assert np.array_equal(uw.enhance(odd, strategy=2, inter_dtype=_lib.INTER_F32T), orc.enhance_u8(odd, 2))
+    # Every route selector under F32T (round 4): the stored-plane route and the overflow fallback evaluate the same
+    # float32 restore, so they give the default route's bytes; the three-digit key sweeps only know the float64 plane, so
+    # select_generic keeps the float64 transmission (= the <= 1 LSB path) instead of reading a float32 plane as doubles.
+    dev = uw.get_device()
+    u8 = frames[0]
+    base = uw.enhance(u8, strategy=2, inter_dtype=_lib.INTER_F32T)
+    for knob in ({"restore_store": 1}, {"lin_cap": 16}, {"lin_no_predict": 1}):
+        with dev.tuning(**knob):
+            assert np.array_equal(uw.enhance(u8, strategy=2, inter_dtype=_lib.INTER_F32T), base), knob
+    with dev.tuning(select_generic=1):
+        assert np.array_equal(uw.enhance(u8, strategy=2, inter_dtype=_lib.INTER_F32T), orc.enhance_u8(u8, 2))
 
 
 def test_boundary_value_frame_from_the_soak_run(uw, orc):

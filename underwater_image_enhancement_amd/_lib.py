@@ -59,6 +59,7 @@ SIGNATURES = {
     "uwie_version": [],
     "uwie_create": [_I, ctypes.POINTER(_VP)],
     "uwie_destroy": [_VP],
+    "uwie_device_status": [_VP, _VP, ctypes.POINTER(ctypes.c_uint32)],
     "uwie_profile_enable": [_VP, _I],
     "uwie_profile_filter": [_VP, ctypes.c_char_p],
     "uwie_profile_collect": [_VP],

@@ -51,10 +51,15 @@ def _as_batch_u8(frames, dev: Device):
     return t.to(dev.torch_device).contiguous(), was_numpy, single
 
 
-def _finish(t, was_numpy, single):
+def _finish(t, was_numpy, single, dev: Device | None = None):
     if single:
         t = t[0]
-    return t.cpu().numpy() if was_numpy else t
+    if not was_numpy:
+        return t
+    out = t.cpu().numpy()
+    if dev is not None:
+        dev.check_status()  # (the copy above synchronised already: this only reads the device's status word)
+    return out
 
 
 def enhance(frames, strategy: int = 2, cast_correct: bool = True, device: int | None = None, return_float: bool = False,
@@ -69,7 +74,7 @@ def enhance(frames, strategy: int = 2, cast_correct: bool = True, device: int | 
     batch, was_numpy, single = _as_batch_u8(frames, dev)
     p = dev.params(_lib.SURFACE_SIX, int(strategy), cast_correct=int(bool(cast_correct)), **overrides)
     out, outf = dev.enhance_u8(batch, p, want_float=return_float)
-    return _finish(outf if return_float else out, was_numpy, single)
+    return _finish(outf if return_float else out, was_numpy, single, dev)
 
 
 # ------------------------------------------------------------------ the batch driver's fan-out (six_stadigy.py:330-520)
@@ -92,15 +97,27 @@ def enhance_all(frames, cast_correct: bool = True, device: int | None = None):
     batch, was_numpy, single = _as_batch_u8(frames, dev)
     out, kind = dev.enhance_all_u8(batch, cast_correct)
     types = [CAST_NAMES[int(k)] for k in kind.cpu().tolist()]
-    outs = {name: _finish(out[i], was_numpy, single) for i, (name, _) in enumerate(DRIVER_STRATEGIES)}
+    outs = {name: _finish(out[i], was_numpy, single, dev) for i, (name, _) in enumerate(DRIVER_STRATEGIES)}
     return outs, types
 
 
-def process_batch(frames, filenames=None, device: int | None = None, compute=None):
-    """Host mirror of the driver's bookkeeping (six_stadigy.py:369-500) for frames that are already decoded: returns
+def process_batch(frames, filenames=None, device: int | None = None, compute=None, compute_one=None):
+    """Host mirror of the driver's bookkeeping (six_stadigy.py:369-520) for frames that are already decoded: returns
     ``(outputs, log_rows, stats)`` where ``log_rows`` has one dict per (image, strategy) with the driver's columns
-    (``filename, image_type, strategy, strategy_desc, status, processing_time``) and ``stats`` its counters.  File
-    I/O (glob / imread / imwrite / CSV) stays with the caller.  ``compute`` (tests) replaces ``enhance_all``.
+    (``filename, image_type, strategy, strategy_desc, status, output_path, processing_time``) and ``stats`` its counters.
+    File I/O (glob / imread / imwrite / CSV) stays with the caller: ``output_path`` is empty for a success (the caller
+    fills it in when it writes the file) and ``"Error: <first 50 characters>"`` for a failure, as in S6:464-478.
+
+    The whole batch goes through ONE fused call (``enhance_all``: one cast detection and one quadtree per frame).  Failure
+    handling follows the reference's two ``try`` levels (S6:395,424): if the fused call raises, every image is retried on
+    its own; if an image's fused call raises, its six strategies run one by one, and a strategy that raises becomes a row
+    with ``status='failed'``, ``processing_time='N/A'`` and counts in ``failed_outputs`` while the other five still succeed
+    (S6:464-480); an image none of whose strategies succeeds counts in ``failed_images`` (S6:484-488), and one whose cast
+    detection itself fails gets no rows at all (S6:508-510).  ``processing_time`` of a success is the time since the image
+    started (S6:457): the image's share of the fused call, or the running time of the one-by-one fallback.
+    ``outputs[name]`` is a list with one uint8 frame (or ``None`` for a failed output) per image.
+    ``frames``: ``[B,H,W,3]`` uint8 or a list of ``[H,W,3]`` frames (frames of different sizes run image by image).
+    ``compute`` / ``compute_one`` (tests) replace ``enhance_all(frames)`` / ``enhance(frame, strategy=k)``.
     """
     import time
 
@@ -108,20 +125,80 @@ def process_batch(frames, filenames=None, device: int | None = None, compute=Non
     filenames = list(filenames) if filenames is not None else [f"frame_{i:05d}" for i in range(n)]
     if len(filenames) != n:
         raise ValueError("one filename per frame")
+    run_all = compute or (lambda f: enhance_all(f, device=device))
+    run_one = compute_one or (lambda f, k: enhance(f, strategy=k, device=device))
     stats = {"total_images": n, "processed_images": 0, "failed_images": 0, "total_outputs": 0, "successful_outputs": 0,
              "failed_outputs": 0, "image_types": {"greenish": 0, "bluish": 0, "normal": 0}}
-    t0 = time.time()
-    outs, types = (compute or (lambda f: enhance_all(f, device=device)))(frames)
-    per_image = (time.time() - t0) / max(n, 1)
+    names = [name for name, _ in DRIVER_STRATEGIES]
+    outs = {name: [None] * n for name in names}
+    # per image: (image_type, [(ok, time string or error message)] * 6) or None when the image failed before its strategy loop
+    results = [None] * n
+
+    def fused(idx, batch):
+        t0 = time.time()
+        o, types = run_all(batch)
+        share = (time.time() - t0) / max(len(idx), 1)
+        for j, i in enumerate(idx):
+            for name in names:
+                outs[name][i] = o[name][j]
+            results[i] = (types[j], [(True, f"{share:.2f}s")] * len(names))
+
+    def one_by_one(i):
+        frame = frames[i]
+        t0 = time.time()
+        x = np.asarray(frame.cpu() if hasattr(frame, "cpu") else frame)
+        try:
+            # (the image_type column only; the strategies detect the cast again themselves, with the same result)
+            kind = detect_image_type(x, device=device) if compute_one is None else "normal"
+        except Exception:  # noqa: BLE001 - S6:508: the image fails as a whole
+            return
+        rows = []
+        for k, name in enumerate(names, start=1):
+            try:
+                outs[name][i] = run_one(frame, k)
+                rows.append((True, f"{time.time() - t0:.2f}s"))
+            except Exception as e:  # noqa: BLE001 - S6:464: any failure of a strategy is a failed row
+                outs[name][i] = None
+                rows.append((False, str(e)[:50]))
+        results[i] = (kind, rows)
+
+    uniform = hasattr(frames, "shape") or len({tuple(np.shape(f)) for f in frames}) <= 1
+    done = False
+    if uniform and n > 0:
+        try:
+            batch = frames if hasattr(frames, "shape") else np.stack([np.asarray(f) for f in frames])
+            fused(list(range(n)), batch)
+            done = True
+        except Exception:  # noqa: BLE001
+            done = False
+    if not done:
+        for i in range(n):
+            try:
+                f = frames[i]
+                fused([i], f[None] if hasattr(f, "shape") else np.asarray(f)[None])
+            except Exception:  # noqa: BLE001
+                one_by_one(i)
+
     rows = []
-    for i, name in enumerate(filenames):
-        stats["image_types"][types[i]] += 1
-        for sname, sdesc in DRIVER_STRATEGIES:
-            rows.append({"filename": name, "image_type": types[i], "strategy": sname, "strategy_desc": sdesc,
-                         "status": "success", "processing_time": f"{per_image:.2f}s"})
-            stats["successful_outputs"] += 1
-            stats["total_outputs"] += 1
-        stats["processed_images"] += 1
+    for i, fname in enumerate(filenames):
+        if results[i] is None:
+            stats["failed_images"] += 1
+            continue
+        kind, per = results[i]
+        stats["image_types"][kind] += 1
+        good = 0
+        for (sname, sdesc), (ok, info) in zip(DRIVER_STRATEGIES, per):
+            if ok:
+                rows.append({"filename": fname, "image_type": kind, "strategy": sname, "strategy_desc": sdesc,
+                             "status": "success", "output_path": "", "processing_time": info})
+                stats["successful_outputs"] += 1
+                good += 1
+            else:
+                rows.append({"filename": fname, "image_type": kind, "strategy": sname, "strategy_desc": sdesc,
+                             "status": "failed", "output_path": f"Error: {info}", "processing_time": "N/A"})
+                stats["failed_outputs"] += 1
+        stats["processed_images" if good else "failed_images"] += 1
+        stats["total_outputs"] += len(DRIVER_STRATEGIES)
     return outs, rows, stats
 
 

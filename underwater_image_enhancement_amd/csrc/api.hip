@@ -64,7 +64,8 @@ const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::
                            {"select_generic", &Tuning::select_generic}, {"restore_store", &Tuning::restore_store},
                            {"lin_predict3", &Tuning::lin_predict3}, {"lin_cap", &Tuning::lin_cap},
                            {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
-                           {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass}};
+                           {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass},
+                           {"canny_fault_inject", &Tuning::canny_fault_inject}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only
 {
@@ -235,7 +236,8 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
     const int k = p->strategy;
     UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, (float)p->omega, 1e-6f, 1, P.t0, st));
     int t_is_f32 = 0;
-    UWIE_TRY(stage_guided(ctx, P, s, p, st, &t_is_f32));
+    // (the three-digit key sweeps of tuning select_generic instantiate the restore for the float64 plane only: no float32 t there)
+    UWIE_TRY(stage_guided(ctx, P, s, p, st, tune().select_generic ? nullptr : &t_is_f32));
     // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
     SelectPlan plan;
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
@@ -518,6 +520,8 @@ int uwie_create(int device, uwie_ctx **out_ctx)
     build_cast_tables(cast);
     hipError_t e = hipMalloc((void **)&ctx->d_lab, sizeof(LabTables));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_cast, sizeof(CastTables));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, 64);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_lab, lab, sizeof(LabTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_cast, cast, sizeof(CastTables), hipMemcpyHostToDevice);
     delete lab;
@@ -536,6 +540,7 @@ void uwie_destroy(uwie_ctx *ctx)
     if (!ctx) return;
     if (ctx->d_lab) (void)hipFree(ctx->d_lab);
     if (ctx->d_cast) (void)hipFree(ctx->d_cast);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->aux_ready) {
         for (int i = 0; i < 4; ++i) {
             (void)hipStreamDestroy(ctx->aux[i]);
@@ -546,6 +551,24 @@ void uwie_destroy(uwie_ctx *ctx)
     prof_bind(nullptr);
     prof_destroy(ctx->prof);
     delete ctx;
+}
+
+int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits)
+{
+    UWIE_REQUIRE(ctx != nullptr, "device_status: NULL context");
+    UWIE_SCOPE(ctx);
+    uint32_t v = 0;
+    hipStream_t st = (hipStream_t)stream;
+    UWIE_HIP_CHECK(hipMemcpyAsync(&v, ctx->d_status, sizeof v, hipMemcpyDeviceToHost, st));
+    UWIE_HIP_CHECK(hipStreamSynchronize(st));
+    if (v) UWIE_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof v, st));
+    if (bits) *bits = v;
+    if (v) {
+        set_error("device status 0x%x:%s the results of the calls since the last check are not valid", v,
+                  (v & UWIE_STATUS_CANNY_LABEL) ? " Canny hysteresis met a component label that this launch did not write (k_canny.hip);" : "");
+        return UWIE_E_DEVICE;
+    }
+    return UWIE_OK;
 }
 
 int uwie_profile_enable(uwie_ctx *ctx, int on)

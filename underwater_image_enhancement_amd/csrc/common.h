@@ -100,6 +100,7 @@ struct Tuning {
     int lin_predict_shift = 0;  // predicted windows moved by this many bins (large: every prediction misses)
     int streams = 1;            // uwie_enhance_u8: sub-batches on this many internal streams (1 .. 4)
     int canny_prepass = 1;      // quadtree: the streaming "any strong pixel?" pass before Canny
+    int canny_fault_inject = 0; // tests only: k_canny_gradnms leaves out the root labels (the round-3 defect): uwie_device_status must report it
 };
 const Tuning &tune();  // tuning of the context whose entry point is running on this host thread (defaults outside one)
 uwie_ctx *current_ctx();
@@ -114,6 +115,7 @@ struct uwie_ctx {
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;
     uwie::Profiler *prof;
+    uint32_t *d_status = nullptr;  // device status word: UWIE_STATUS_* bits set by kernels that find an invariant violated
     // two-way batch pipelining (uwie_enhance_u8): helper streams and the fork / join events, created on first use
     hipStream_t aux[4];
     hipEvent_t fork, join[4];

@@ -52,6 +52,8 @@ struct CannyBufs {
     uint32_t *count;   // [region] edge counts, or nullptr
     uint32_t *nstrong; // (WEAKONLY) strong pixels per tile, [tile]: k_canny_emit adds them to the counts
     int tiles;         // tiles per region in this launch
+    uint32_t *status;  // the context's device status word (uwie_device_status) or nullptr: walkers report a bad label there
+    int inject;        // tests only (tuning canny_fault_inject): roots do not get their own label -- the round-3 defect
 };
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -481,7 +483,15 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
             const int b = __ffs(km) - 1, li = (2 * rp + (b >> 2)) * kCT_W + 4 * cg + (b & 3);
             const int p = (r.y0 + ry0 + (b >> 2)) * W + r.x0 + rx0 + (b & 3);
             bufs.flag[base + p] = 0;
-            if constexpr (WEAKONLY) bufs.label[base + p] = p;  // the root itself may be an interior pixel: the links of its border members end here
+            // The root itself may be an interior pixel, which gets no list slot and therefore no label above: the links of its
+            // border members end here, so it needs its own.  INVARIANT: every label that can be reached
+            // from a list entry of this launch is written in this launch -- label[] is never cleared, so anything else found
+            // there is a stale index of an earlier level or frame size.  (Round 3's two memory access faults, on the hazy and
+            // uniform 4K x 64 benches between 8c71da7 and 338471a, were this store missing: k_canny_mark / k_canny_emit walked
+            // from a border member to the root's pixel and on through whatever the previous level had left there.)
+            if constexpr (WEAKONLY) {
+                if (!bufs.inject) bufs.label[base + p] = p;
+            }
             uint32_t info = dense ? s_info[li] : part_info(b);
             if constexpr (WEAKONLY) info = (info & 0xfffu) | (((info >> 12) & 0xfffu) ? 0x10000u : 0u);  // {size, on}
             *dst++ = make_uint2((uint32_t)p, info);
@@ -489,33 +499,47 @@ __global__ void __launch_bounds__(256) k_canny_gradnms(const uint8_t *__restrict
     }
 }
 
-__device__ __forceinline__ int ld_label(const int32_t *L, int i)
+// Parent of pixel i (i is a valid index of the frame).  Links only ever point to a SMALLER index or to the pixel itself, so a
+// parent above i -- or a negative one, which is above every index as an unsigned number -- cannot have been written by this
+// launch: it is reported in the context's status word (uwie_device_status -> UWIE_E_DEVICE) and i is taken as a root.  With
+// this every index a walker dereferences is inside the frame and every walk is strictly decreasing, whatever the label
+// plane holds: a violated invariant is an error code, never a memory access fault or a hang.
+__device__ __forceinline__ int ld_label(const int32_t *L, int i, uint32_t *status)
 {
-    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int p = __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)p > (uint32_t)i) {
+        if (status) atomicOr(status, (uint32_t)UWIE_STATUS_CANNY_LABEL);
+        return i;
+    }
+    return p;
 }
 
 // Root of i with path halving.  Parent links only ever decrease, so a stale read is still an ancestor.
-__device__ int uf_find(int32_t *L, int i)
+__device__ int uf_find(int32_t *L, int i, uint32_t *status)
 {
     for (;;) {
-        const int p = ld_label(L, i);
+        const int p = ld_label(L, i, status);
         if (p == i) return i;
-        const int gp = ld_label(L, p);
+        const int gp = ld_label(L, p, status);
         if (gp == p) return p;
         atomicMin(L + i, gp);
         i = gp;
     }
 }
 
-__device__ void uf_union(int32_t *L, int a, int b)
+__device__ void uf_union(int32_t *L, int a, int b, uint32_t *status)
 {
     for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
+        a = uf_find(L, a, status);
+        b = uf_find(L, b, status);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }
         const int old = atomicCAS(L + a, a, b);  // link the larger root under the smaller one
         if (old == a) return;
+        if ((uint32_t)old > (uint32_t)a) {  // not a label of this launch (see ld_label): nothing to continue from
+            if (status) atomicOr(status, (uint32_t)UWIE_STATUS_CANNY_LABEL);
+            return;
+        }
         a = old;  // somebody re-parented `a` first: continue from its new parent
     }
 }
@@ -569,13 +593,13 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
     int32_t *L = bufs.label + base;
     auto link = [&](int p, int q) {
         // the labels written by k_canny_gradnms are the tile-local roots: start from them (any ancestor will do)
-        int a = ld_label(L, p), b = ld_label(L, q);
+        int a = ld_label(L, p, bufs.status), b = ld_label(L, q, bufs.status);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }
         const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
         const uint32_t slot = ((uint32_t)a * 0x9e3779b1u ^ (uint32_t)b * 0x85ebca6bu) >> 23;
         if (atomicExch(&s_seen[slot], key) == key) return;
-        uf_union(L, a, b);
+        uf_union(L, a, b, bufs.status);
     };
     for_list(bufs.nborder, bufs.tiles, [&](size_t pos) {
         // links inside a tile were made in LDS by k_canny_gradnms: only pairs that straddle a tile border are left
@@ -601,7 +625,7 @@ __global__ void __launch_bounds__(256) k_canny_union(const Region *__restrict__ 
                 if (yd) on = on || cm[p + W] == 2;
                 if (right && (yd || xr)) on = on || cm[p + W + 1] == 2;
             }
-            if (on) bufs.flag[base + ld_label(L, p)] = 1;
+            if (on) bufs.flag[base + ld_label(L, p, bufs.status)] = 1;
             if (right && xr && cm[p + 1] == 0) link(p, p + 1);
             if (down) {
                 if (left && (yd || xl) && cm[p + W - 1] == 0) link(p, p + W - 1);
@@ -630,7 +654,7 @@ __global__ void __launch_bounds__(256) k_canny_mark(const Region *__restrict__ r
         const int p = (int)e.x;
         int root = p;
         for (;;) {
-            const int q = ld_label(L, root);
+            const int q = ld_label(L, root, bufs.status);
             if (q == root) break;
             root = q;
         }
@@ -674,7 +698,11 @@ __global__ void __launch_bounds__(256) k_canny_paint(const Region *__restrict__ 
     const int32_t *L = bufs.label + base;
     for_candidates(bufs, [&](int p) {
         int root = p;
-        while (L[root] != root) root = L[root];
+        for (;;) {
+            const int q = ld_label(L, root, bufs.status);
+            if (q == root) break;
+            root = q;
+        }
         if (bufs.flag[base + root]) edges[base + p] = 255;
     });
 }
@@ -749,6 +777,8 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     const dim3 lgrid(cdiv(cdiv(bufs.tiles, kWalkTiles), 4), nreg);  // list walkers: 4 wavefronts per block
     const bool weakonly = d_count && !d_edges;  // counts only: strong pixels need no labelling
     bufs.count = d_count;
+    bufs.status = current_ctx() ? current_ctx()->d_status : nullptr;
+    bufs.inject = tune().canny_fault_inject;
     if (d_count && !count_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * nreg, st));
     if (d_edges) UWIE_HIP_CHECK(hipMemsetAsync(d_edges, 0, (size_t)s.B * s.npx(), st));
     // Pre-pass (edge counts only: the standalone edge map keeps the single pass): regions without a pixel above the high

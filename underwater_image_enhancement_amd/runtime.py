@@ -89,8 +89,9 @@ class Device:
     # ------------------------------------------------------------------ route selectors (uwie_set_tuning)
     def tune(self, **selectors):
         """Set route selectors of this context (include/uwie.h: gf_pipe, gf_split, gf_bands, select_generic, restore_store,
-        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, q_hist, streams, canny_prepass).  Results are the same bytes on
-        every route; tests force the fallback routes with it."""
+        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, q_hist, streams, canny_prepass).  The selection / storage / quadtree
+        selectors give the same bytes on every route, the gf_* ones the same transmission to 1e-11 (uwie.h); tests force the
+        fallback routes with it."""
         for name, value in selectors.items():
             check(self.lib.uwie_set_tuning(self._ctx, name.encode(), int(value)))
 
@@ -112,6 +113,14 @@ class Device:
                 self.tune(**old)
 
         return scope()
+
+    # ------------------------------------------------------------------ device-side self checks (uwie_device_status)
+    def check_status(self):
+        """Wait for the current stream and raise ``UwieError`` if a kernel found one of its invariants violated since the last
+        check (include/uwie.h: UWIE_E_DEVICE) -- the results of those calls are not valid.  ``enhance`` & co. call this when
+        they copy results back to the host (they synchronise there anyway); callers that keep tensors on the device call it
+        when they synchronise."""
+        check(self.lib.uwie_device_status(self._ctx, self.stream(), None))
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
     def profile(self, on: bool, only: str | None = None):
