@@ -43,7 +43,7 @@ KERNEL_BYTES_PER_PX = {
     "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
     "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
     "k_sel_hist<V>": 2 * 3 * 4, "k_restore_hist_collect": 3 + 8 + 12, "k_restore_hist_lin": 3 + 8 + 12,
-    "k_restore_hist_key": 3 + 8 + 12, "k_lin_collect": 12, "k_stretch_lab_lut<1>": 11 + 3, "k_stretch_lab_lut<0>": 12 + 3, "k_clahe_apply_u8": 3 + 3, "k_clahe_apply_f32": 3 + 3 + 12,
+    "k_restore_hist_key": 3 + 8 + 12, "k_restore_rank": 3 + 8, "k_lin_collect": 12, "k_stretch_lab_lut<1>": 11 + 3, "k_stretch_lab_lut<0>": 12 + 3, "k_clahe_apply_u8": 3 + 3, "k_clahe_apply_f32": 3 + 3 + 12,
     "k_stretch_out": 12 + 3, "k_stretch_apply": 12 + 12, "k_quant_rgb2lab": 12 + 3, "k_clahe_lut": 1,
     "k_clahe_apply": 1 + 1, "k_lab2rgb_f32": 3 + 12, "k_gamma": 12 + 12, "k_quantise": 12 + 3,
     "k_normalise_correct": 3 + 12,

@@ -442,7 +442,10 @@ def test_select_paths_agree(uw, orc):
                     with dev.tuning(select_generic=1):
                         check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
                     # the producer files the predicted windows (two, or strategy 3's four): off, still covering, missing
-                    for knob, val in (("lin_no_predict", 1), ("lin_predict_shift", 2), ("lin_predict_shift", 400), ("lin_predict3", 1)):
+                    # (rank_sweep = 0: the histogram sweep of rounds 1-3 instead of round 4's rank-counting sweep, which is the
+                    # default route of strategies 1-2 without stored planes and the one the shifted / missing windows exercise)
+                    for knob, val in (("lin_no_predict", 1), ("lin_predict_shift", 2), ("lin_predict_shift", 400), ("lin_predict3", 1),
+                                      ("rank_sweep", 0)):
                         with dev.tuning(**{knob: val}):
                             check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
             check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")

@@ -65,7 +65,7 @@ const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::
                            {"lin_predict3", &Tuning::lin_predict3}, {"lin_cap", &Tuning::lin_cap},
                            {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
                            {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass},
-                           {"canny_fault_inject", &Tuning::canny_fault_inject}};
+                           {"canny_fault_inject", &Tuning::canny_fault_inject}, {"rank_sweep", &Tuning::rank_sweep}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only
 {
@@ -262,9 +262,15 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // Tuning lin_predict3 brings the windows back.
         const bool predict = k != 3 || tune().lin_predict3;
         UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, predict ? &src : nullptr));
-        UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
-                                            &plan, t_is_f32));
-        UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
+        if (recompute && plan.predicted && !t_is_f32 && tune().rank_sweep) {
+            // round 4: no histogram at all -- counts below the predicted windows + the windows' members (k_restore_rank)
+            UWIE_TRY(launch_restore_rank(src, s, plan, st));
+            UWIE_TRY(select_rank_run(plan, P.F, s, st, src));
+        } else {
+            UWIE_TRY(launch_restore_planar_hist(d_in, kind, P.A, P.t, s, recompute ? nullptr : P.F, plan.ghist, st, true, nullptr,
+                                                &plan, t_is_f32));
+            UWIE_TRY(select_lin_run(plan, P.F, s, st, recompute ? &src : nullptr));
+        }
     }
     if (k == 3) {
         UWIE_TRY(select_lerp_chain(plan, s, eps, P.pct, st));

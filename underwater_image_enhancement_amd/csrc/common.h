@@ -100,6 +100,7 @@ struct Tuning {
     int lin_predict_shift = 0;  // predicted windows moved by this many bins (large: every prediction misses)
     int streams = 1;            // uwie_enhance_u8: sub-batches on this many internal streams (1 .. 4)
     int canny_prepass = 1;      // quadtree: the streaming "any strong pixel?" pass before Canny
+    int rank_sweep = 1;         // strategies 1-2: the rank-counting restore sweep (0: the histogram sweep)
     int canny_fault_inject = 0; // tests only: k_canny_gradnms leaves out the root labels (the round-3 defect): uwie_device_status must report it
 };
 const Tuning &tune();  // tuning of the context whose entry point is running on this host thread (defaults outside one)
@@ -279,7 +280,9 @@ struct LinState {
     uint32_t ngroups;            // groups the collecting sweep has to fill (0: the prediction covered every query)
     uint32_t wlo[kMaxPct], wspan[kMaxPct];  // predicted windows (one per percentile, merged when they touch): bins
                                             // wlo .. wlo + wspan (wlo = kLinNoWin: none), list = window
+    uint32_t below[kMaxPct];     // (rank-counting sweep, k_restore_rank) elements in the bins below window w
 };
+constexpr uint32_t kLinAnyBin = 0xfffffffeu;  // LinState::qbin: the query's list is its whole window, rr its rank inside it
 struct RestoreSrc;
 // predict != nullptr: the target bins are predicted from a subsample of the restored image (k_lin_sample)
 int select_lin_begin(Shape s, const double *q_percent, int nq, void *ws, hipStream_t st, SelectPlan *plan,
@@ -319,6 +322,9 @@ struct RestoreSrc {
 int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const float *d_A, const double *d_t, Shape s,
                                float *d_planar, uint32_t *d_ghist, hipStream_t st, bool linear = false,
                                const uint32_t *d_only = nullptr, const SelectPlan *plan = nullptr, int t32 = 0);
+// the rank-counting sweep (k_restore_rank): counts below each predicted window + the windows' members, no histogram
+int launch_restore_rank(const RestoreSrc &src, Shape s, const SelectPlan &plan, hipStream_t st);
+int select_rank_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc &src);
 size_t tail_ws_bytes(Shape s, int tx, int ty);
 // d_pct: [B][3][pct_stride] = lo1, hi1 [, lo2, hi2]; two = second stretch present; gamma_mode 0/1/2
 int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, int pct_stride, float eps, int two,

@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
         __syncthreads();
         bool need = force;
         for (int j = 0; j < NS; ++j) need = need || scount[j] > (uint32_t)(SN * 3 / 4);
-        if (!need) return;  // block-uniform
+        __syncthreads();  // nobody files again before everybody has looked (round 4: the decision has to be block-uniform)
+        if (!need) return;
         if (tid < NS) {
             const uint32_t c = min(scount[tid], (uint32_t)SN);
             if (c) sbase[tid] = atomicAdd(&lin[3 * b + tid / NW].gcount[tid % NW], c);
@@ -305,6 +306,272 @@ __global__ void __launch_bounds__(256) k_restore_planar_hist(RestoreSrc S, int n
     }
     RestoreImgT<FAST ? 2 : 0> R;
     sweep(R);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Rank-counting sweep (round 4; six_stadigy.py:183-199): what enhance_contrast needs of the restored image is two order
+// statistics per channel, and k_lin_predict has already bracketed each of them by a window of histogram bins.  So instead
+// of evaluating the float64 restore for every value and histogramming it (k_restore_planar_hist<true, true>: 52 VALU
+// instructions and 9.7 LDS atomics with return per pixel), this sweep
+//   * classifies every value with a CHEAP float32 restore (one fused multiply-add on v_rcp_f32 of the float32 transmission)
+//     against the window edges widened by kRankMargin -- the float32 value is within 4e-6 of the float64 one (|I - A| / t
+//     <= 10: 2^-24 on t, 2^-23 on the reciprocal, half an ulp of a value below 16 on the sum and on the exact value's own
+//     rounding), the margin is 1e-5 = 0.02 bins -- and counts the values definitely BELOW each window with wavefront ballots
+//     (v_cmp into a scalar pair + s_bcnt1: no LDS traffic);
+//   * queues the VALUES that fall inside a widened window (~2 % of them) in LDS and evaluates those, and only those, with the
+//     exact float64 sequence, densely (every lane busy), every eight trips: a value whose exact bin lies below the window adds
+//     to its count, one inside the window goes to the window's list, as in the histogram sweep.
+// k_rank_scan (k_select.hip) then finds each rank in (below, below + list length) and k_lin_finish selects inside the list.
+// A rank outside its window (the sample misled the prediction, ~6e-5 per window), or a list that overflowed, flags the
+// plane for the generic sweeps exactly as before.  Results are the same order statistics: identical bytes.
+// grid (nblk, B), block 256.  float64 transmission only (UWIE_INTER_F32T keeps the histogram sweep: there the float32
+// restore IS the value).
+constexpr float kRankMargin = 1e-5f;
+constexpr int kRankNW = 2, kRankNS = 3 * kRankNW;
+// Everything the exact stage touches is PRIVATE to a wavefront (round 4, second version: the first one queued per block --
+// an LDS atomic with return per lane and trip, six barriers per flush -- and was slower than the histogram sweep it replaces,
+// 2.1 against 1.7 ms, with the same 55 VALU instructions per pixel).  A wavefront appends the values it has to look at exactly
+// to its own queue (positions from ballots: no atomics), evaluates 64 of them at a time -- one per lane -- as soon as it has
+// 64, and stages the window members it finds per (channel, window) until there are 64 to write to the list in one piece.
+// No barrier after the set-up, no LDS atomic in the loop.
+constexpr int kRankQW = 64 + 64 * 12;  // queue entries per wavefront: fewer than 64 left over + at most 12 per lane and trip
+constexpr int kRankSW = 128;           // stage entries per wavefront and (channel, window): flushed when 64 are there
+
+__device__ __forceinline__ void wave_lds_sync()  // LDS executes a wavefront's instructions in order: a compiler fence is all
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// (free functions with everything passed explicitly: as lambdas, the closure of a closure stayed in scratch memory)
+struct RankWave {  // what one wavefront's exact stage works with
+    const uint8_t *img;
+    const double *t;
+    const float *ftab;              // LDS: I - A as float32, [3][256]
+    float a0, a1, a2;
+    const uint32_t *s_wlo, *s_wspan;  // LDS
+    const float *s_lo, *s_hi;
+    uint32_t *s_below;
+    uint32_t *myq;                  // LDS: this wavefront's queue
+    float (*mystg)[kRankSW];        // LDS: this wavefront's stages
+    uint32_t *gcount0;              // &lin[3 b].gcount[0]; channel c is c * gstride words further
+    uint32_t gstride;
+    float *lists0;                  // the lists of (3 b, window 0)
+    uint32_t cap;
+    int lane;
+};
+
+// the whole wavefront: the n <= 128 entries of stage j go to their list in one piece
+__device__ __forceinline__ void rank_flush_stage(const RankWave &X, int j, uint32_t &scj)
+{
+    const uint32_t n = scj;
+    const int c = j / kRankNW, w = j % kRankNW;
+    uint32_t base = 0;
+    if (X.lane == 0) base = atomicAdd(X.gcount0 + (size_t)c * X.gstride + w, n);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    float *L = X.lists0 + ((size_t)c * kLinLists + w) * X.cap;
+    wave_lds_sync();
+    for (uint32_t i = X.lane; i < n; i += 64)
+        if (base + i < X.cap) L[base + i] = X.mystg[j][i];
+    wave_lds_sync();
+    scj = 0;
+}
+
+// lanes < m evaluate queue entries first .. first + m - 1 exactly: restore_image's float64 sequence (restore.h one_fast /
+// one, written out with the channel's constants selected by value).  counted: the ballots have seen the value's float32
+// image -- "not below" for the window it was queued for (exact: below or inside), definite and right for the other one.
+__device__ __forceinline__ void rank_exact_batch(const RankWave &X, uint32_t first, uint32_t m, bool counted, uint32_t (&sc)[kRankNS])
+{
+    wave_lds_sync();
+    int jj = -1;  // the (channel, window) this lane's value turned out to belong to, -1: none
+    float x = 0.0f;
+    if ((uint32_t)X.lane < m) {
+        const uint32_t e = X.myq[first + X.lane];
+        const int p = (int)(e >> 2), c = (int)(e & 3u);
+        const double tv = X.t[p];
+        const uint32_t u = X.img[(size_t)p * 3 + c];
+        const float df = X.ftab[c * 256 + (int)u], ac = c == 0 ? X.a0 : c == 1 ? X.a1 : X.a2;
+        const double n = (double)df;
+        double q;
+        if (RestoreImgT<1>::recip_ok(tv)) {
+            const double y = RestoreImgT<1>::recip(tv), q0 = n * y;
+            q = fma(fma(-tv, q0, n), y, q0);
+        } else {
+            q = n / tv;
+        }
+        x = clip01((float)(q + (double)ac));  // S6:186-188
+        const uint32_t d = lin_digit(x);
+        const float v32 = fmaf(df, __builtin_amdgcn_rcpf((float)tv), ac);
+#pragma unroll
+        for (int w = 0; w < kRankNW; ++w) {
+            const int j = c * kRankNW + w;
+            const uint32_t wlo = X.s_wlo[j];
+            if (wlo == kLinNoWin) continue;
+            if (counted && !(v32 >= X.s_lo[j] && v32 <= X.s_hi[j])) continue;  // not queued for this window
+            if (d < wlo) atomicAdd(&X.s_below[j], 1u);  // (rare: the margin's width under the window, or the ragged tail)
+            else if (d - wlo <= X.s_wspan[j]) jj = j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kRankNS; ++j) {
+        const uint64_t mk = __ballot(jj == j);
+        if (mk) {  // uniform
+            const uint32_t pos = sc[j] + (uint32_t)__popcll(mk & ((1ull << X.lane) - 1));
+            if (jj == j) X.mystg[j][pos] = x;
+            sc[j] += (uint32_t)__popcll(mk);
+            if (sc[j] >= 64u) rank_flush_stage(X, j, sc[j]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_restore_rank(RestoreSrc S, int npx, LinState *__restrict__ lin, float *__restrict__ lists,
+                                                      uint32_t cap)
+{
+    constexpr int NW = kRankNW, NS = kRankNS, QW = kRankQW, SW = kRankSW;
+    __shared__ uint32_t wq[4][QW];     // (pixel << 2) | channel of the values to evaluate exactly
+    __shared__ float wstg[4][NS][SW];
+    __shared__ float ftab[768];
+    __shared__ uint32_t s_wlo[NS], s_wspan[NS];  // the windows in bins (s_wlo = kLinNoWin: none)
+    __shared__ float s_lo[NS], s_hi[NS];         // their edges as values, widened by the margin
+    __shared__ uint32_t s_below[NS];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < NS) {
+        s_below[tid] = 0;
+        const LinState &L = lin[3 * b + tid / NW];
+        const uint32_t lo = L.wlo[tid % NW], span = L.wspan[tid % NW];
+        s_wlo[tid] = lo;
+        s_wspan[tid] = span;
+        // bin d holds ((d - 1) / 2048, d / 2048) [d = 1: (0, 1/2048)]; no window: nothing is inside, everything "below"
+        s_lo[tid] = lo == kLinNoWin ? __builtin_inff() : (float)(lo - 1) * (1.0f / 2048.0f) - kRankMargin;
+        s_hi[tid] = lo == kLinNoWin ? -__builtin_inff() : (float)(lo + span) * (1.0f / 2048.0f) + kRankMargin;
+    }
+    RestoreImgT<1> R;
+    R.init(S, b, (size_t)npx, ftab);
+    __syncthreads();
+    // (in vector registers on purpose: as scalars the twelve edges, the compare masks of a group and the six counters do not
+    // fit the 102 scalar registers, and the first build moved them through v_readlane / v_writelane all the time)
+    float elo[NS], ehi[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        elo[j] = s_lo[j];
+        ehi[j] = s_hi[j];
+    }
+    const float a0 = R.a[0], a1 = R.a[1], a2 = R.a[2];
+    const uint8_t *img = S.in + (size_t)b * npx * 3;
+    const double *tpl = S.t + (size_t)b * npx;
+    uint32_t *myq = wq[wv];
+    uint32_t cnt[NS] = {0, 0, 0, 0, 0, 0};  // values definitely NOT below each window: wavefront totals
+    uint32_t seen = 0;                       // values per channel the ballots have seen (uniform)
+    uint32_t qn = 0;                         // entries in this wavefront's queue (uniform)
+    uint32_t sc[NS] = {0, 0, 0, 0, 0, 0};    // entries in its stages (uniform)
+
+    const RankWave X{img, tpl, ftab, a0, a1, a2, s_wlo, s_wspan, s_lo, s_hi, s_below, myq, wstg[wv],
+                     &lin[3 * b].gcount[0], (uint32_t)(sizeof(LinState) / sizeof(uint32_t)),
+                     lists + (size_t)(3 * b) * kLinLists * cap, cap, lane};
+
+    const int step = gridDim.x * 1024, iters = (npx + step - 1) / step;  // block-uniform trip count
+    typedef uint32_t __attribute__((aligned(1))) u32_a1;
+#define UWIE_RANK_LOAD4(p_, w_, tv_)                                                                                   \
+    do {                                                                                                                \
+        const u32_a1 *q_ = reinterpret_cast<const u32_a1 *>(img + (size_t)(p_) * 3);                                    \
+        (w_)[0] = q_[0]; (w_)[1] = q_[1]; (w_)[2] = q_[2];                                                              \
+        const double2_a8 ta_ = *reinterpret_cast<const double2_a8 *>(tpl + (p_)),                                       \
+                         tb_ = *reinterpret_cast<const double2_a8 *>(tpl + (p_) + 2);                                   \
+        (tv_)[0] = ta_.x; (tv_)[1] = ta_.y; (tv_)[2] = tb_.x; (tv_)[3] = tb_.y;                                         \
+    } while (0)
+    uint32_t w_nx[3] = {0, 0, 0};
+    double tv_nx[4] = {1.0, 1.0, 1.0, 1.0};
+    bool have_nx = false;
+    {
+        const int p0 = (blockIdx.x * 256 + tid) * 4;
+        have_nx = p0 + 4 <= npx;
+        if (have_nx) UWIE_RANK_LOAD4(p0, w_nx, tv_nx);
+    }
+    for (int it = 0; it < iters; ++it) {
+        const int p = it * step + (blockIdx.x * 256 + tid) * 4;
+        const bool have = have_nx;
+        const uint32_t w0 = w_nx[0], w1 = w_nx[1], w2 = w_nx[2];
+        const double tv[4] = {tv_nx[0], tv_nx[1], tv_nx[2], tv_nx[3]};
+        {
+            const int pn = p + step;
+            have_nx = it + 1 < iters && pn + 4 <= npx;
+            if (have_nx) UWIE_RANK_LOAD4(pn, w_nx, tv_nx);
+        }
+        uint32_t fm = 0;  // bit 4 c + i: value i of channel c lies in a widened window
+        seen += 4u * (uint32_t)__popcll(__ballot(have));
+        if (have) {
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = __builtin_amdgcn_rcpf((float)tv[i]);
+            const uint32_t ub[3][4] = {{w0 & 255, w0 >> 24, (w1 >> 16) & 255, (w2 >> 8) & 255},
+                                       {(w0 >> 8) & 255, w1 & 255, w1 >> 24, (w2 >> 16) & 255},
+                                       {(w0 >> 16) & 255, (w1 >> 8) & 255, w2 & 255, w2 >> 24}};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float ac = c == 0 ? a0 : c == 1 ? a1 : a2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaf(ftab[c * 256 + (int)ub[c][i]], y[i], ac);
+                    bool in = false;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        // counted: the values NOT below the window (v >= edge), so that the same compare serves the membership
+                        // test (written as !(v < edge) it cost a second compare: 71 instead of 48 per group)
+                        const bool ge = v >= elo[c * NW + w];
+                        cnt[c * NW + w] += (uint32_t)__popcll(__ballot(ge));
+                        in = in | (ge & (v <= ehi[c * NW + w]));
+                    }
+                    fm |= (uint32_t)in << (4 * c + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one channel's masks at a time (scalar register budget)
+            }
+        }
+        // the ragged last group of the frame: exact, NOT in the ballot counts (at most one lane per frame)
+        const bool ragged = !have && p < npx;
+        // ---- append this trip's values to the wavefront's queue: positions from ballots
+        const uint32_t nmine = (uint32_t)__popc(fm);
+        if (__ballot(nmine != 0)) {
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {  // nmine <= 12
+                const uint64_t mk = __ballot((nmine >> bit) & 1u);
+                pre += (uint32_t)__popcll(mk & ((1ull << lane) - 1)) << bit;
+                tot += (uint32_t)__popcll(mk) << bit;
+            }
+            uint32_t at = qn + pre;
+            for (uint32_t f = fm; f; f &= f - 1, ++at) {
+                const int k = __ffs(f) - 1;
+                myq[at] = ((uint32_t)(p + (k & 3)) << 2) | (uint32_t)(k >> 2);
+            }
+            qn += tot;
+            while (qn >= 64u) {  // uniform
+                qn -= 64u;
+                rank_exact_batch(X, qn, 64u, true, sc);
+            }
+        }
+        if (__ballot(ragged)) {  // uniform; the lanes' own queue area above the live entries serves as scratch
+            const uint32_t n3 = ragged ? (uint32_t)(npx - p) * 3u : 0u;  // <= 9 values
+            wave_lds_sync();
+            if (ragged)
+                for (uint32_t i = 0; i < n3; ++i) myq[qn + i] = ((uint32_t)(p + (int)(i / 3u)) << 2) | (i % 3u);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)n3, (int)__builtin_ctzll(__ballot(ragged))));
+            rank_exact_batch(X, qn, m, false, sc);
+        }
+    }
+    if (qn) rank_exact_batch(X, 0u, qn, true, sc);
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+        if (sc[j]) rank_flush_stage(X, j, sc[j]);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        uint32_t k = cnt[j];  // the wavefront's total sits in the lanes that took part in every trip (lane 0 did): the maximum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, o));
+        if (lane == 0 && seen != k) atomicAdd(&s_below[j], seen - k);  // below = seen - not below
+    }
+    __syncthreads();
+    if (tid < NS && s_below[tid]) atomicAdd(&lin[3 * b + tid / NW].below[tid % NW], s_below[tid]);
 }
 
 struct Stretch {  // per image: lo and denominator per channel, for one or two chained stretches
@@ -1140,6 +1407,19 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
         UWIE_LAUNCH(k_restore_hist_key, grid, dim3(256), 0, st, S, (int)s.npx(), d_planar, d_ghist, d_only,
                     (LinState *)nullptr, (float *)nullptr, 0u);
     }
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+int launch_restore_rank(const RestoreSrc &src, Shape s, const SelectPlan &plan, hipStream_t st)
+{
+    UWIE_REQUIRE(!src.t32 && plan.nq <= 2 && plan.predicted, "restore_rank: float64 transmission, two predicted percentiles");
+    // 25.5 KB of LDS per block.  Blocks per frame as for the histogram sweep (several full rounds of the chip).
+    int nblk = cdiv(12288, s.B);
+    nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
+    const int need = cdiv((long long)s.npx(), 1024);
+    if (nblk > need) nblk = need;
+    UWIE_LAUNCH(k_restore_rank, dim3(nblk, s.B), dim3(256), 0, st, src, (int)s.npx(), (LinState *)plan.lin, plan.lists, plan.cap);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

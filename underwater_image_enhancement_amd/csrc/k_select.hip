@@ -508,6 +508,7 @@ __global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, 
         for (int w = 0; w < kMaxPct; ++w) {
             s.wlo[w] = wl[w];
             s.wspan[w] = wl[w] == kLinNoWin ? 0 : wh[w] - wl[w];
+            s.below[w] = 0;
         }
         st[bc] = s;
     }
@@ -567,6 +568,49 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
         st[bc] = s;
         flags[bc] = 0;
     }
+}
+
+// After the rank-counting sweep (k_restore_rank): one thread per (image, channel).  Window w holds the elements of bins
+// wlo .. wlo + wspan in its list (gcount of them) and `below` elements lie in the bins under it, so rank r belongs to the
+// window with below <= r < below + gcount, at position r - below of its list.  Bins 0 and kLinBins - 1 hold exact zeros and
+// exact ones only: a rank under a window that starts at bin 1 is 0, one above a window that ends at bin 2048 is 1.  Anything
+// else -- the prediction missed, or the list overflowed -- flags the plane for the generic sweeps.
+__global__ void k_rank_scan(LinState *__restrict__ st, RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags,
+                            uint32_t cap, int nbc)
+{
+    const int bc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bc >= nbc) return;
+    LinState s = st[bc];
+    bool miss = false;
+    for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.qbin[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; }
+    for (int q = 0; q < ranks.n; ++q) {
+        const uint32_t r = ranks.r[q];
+        bool done = false;
+        for (int w = 0; w < kMaxPct && !done; ++w) {
+            if (s.wlo[w] == kLinNoWin) continue;
+            const uint32_t below = s.below[w], cnt = s.gcount[w];
+            if (r >= below && r - below < cnt) {
+                if (cnt <= cap) {
+                    s.gid[q] = (uint32_t)w;
+                    s.rr[q] = r - below;
+                    s.qbin[q] = kLinAnyBin;
+                } else {
+                    miss = true;
+                }
+                done = true;
+            } else if (r < below && s.wlo[w] == 1u) {
+                os[bc * kMaxRanks + q] = 0.0f;
+                done = true;
+            } else if (r >= below && s.wlo[w] + s.wspan[w] == (uint32_t)kLinBins - 2u) {
+                os[bc * kMaxRanks + q] = 1.0f;
+                done = true;
+            }
+        }
+        miss = miss || !done;
+    }
+    s.ngroups = 0;
+    st[bc] = s;
+    flags[bc] = miss ? 1u : 0u;
 }
 
 // grid (blocks, B*3): one sweep over the plane; elements whose bin is a target bin go to that group's list.  A block
@@ -759,15 +803,29 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
 // elements spread evenly.
 template <typename V>
 __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const V *__restrict__ lists,
-                                                     uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags)
+                                                     uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags, int pair)
 {
     using K = typename Traits<V>::K;
     constexpr int kBuf = 49152 / (int)sizeof(V);
     __shared__ uint32_t h[2048], wsum[16], found[2], s_nloc;
     __shared__ unsigned long long s_kmin, s_kmax;
     __shared__ V s_buf[kBuf];
-    const int bc = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63;  // grid (B*3, ranks)
+    const int bc = blockIdx.x, tid = threadIdx.x, lane = tid & 63;  // grid (B*3, ranks)
     const LinState *s = st + bc;
+    // pair: blocks 0 .. ranks/2 - 1 take the even queries (and their successor when it is the next element of the same list),
+    // blocks ranks/2 .. the odd queries that are not such successors
+    int q = blockIdx.y;
+    if (pair) {
+        const int half = (int)gridDim.y / 2;
+        if (q < half) {
+            q = 2 * q;
+        } else {
+            q = 2 * (q - half) + 1;
+            if (s->gid[q] != kLinDone && s->gid[q] == s->gid[q - 1] && s->qbin[q] == s->qbin[q - 1] && s->rr[q] - s->rr[q - 1] <= 1u)
+                return;  // its predecessor's block answers it
+        }
+    }
+    const bool with_next = pair && !(q & 1);
     const uint32_t g = s->gid[q];
     if (g == kLinDone) return;  // block-uniform: answered by the scan
     const uint32_t cnt = s->gcount[g];
@@ -795,7 +853,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool mine = lin_digit(x[u]) == tb;
+                const bool mine = tb == kLinAnyBin ? base + u * 1024 + tid < cnt : lin_digit(x[u]) == tb;
                 const uint64_t m = __ballot(mine);
                 if (m) {  // wavefront-aggregated append
                     const int leader = (int)__builtin_ctzll(m);
@@ -847,7 +905,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
                     x[u] = i < cnt ? L[i] : (V)-1;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) take(x[u], lin_digit(x[u]) == tb);
+                for (int u = 0; u < 8; ++u) take(x[u], tb == kLinAnyBin ? base + u * 1024 + tid < cnt : lin_digit(x[u]) == tb);
             }
         }
         __syncthreads();
@@ -858,6 +916,55 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         lo = shift;
     }
     if (tid == 0) os[bc * kMaxRanks + q] = Traits<V>::value((K)prefix);
+    // pair != 0 (grid.y = queries / 2): the block also answers query q + 1 when it is the NEXT order statistic of the same
+    // list (np.percentile's two neighbours, S6:196-197): one more pass -- how many elements are <= x_r, and the smallest one
+    // above it -- instead of a second block repeating the whole select.
+    if (!with_next) return;
+    const int q1 = q + 1;
+    if (s->gid[q1] != g || s->qbin[q1] != tb || s->rr[q1] - s->rr[q] > 1u) return;  // (answered by its own block: see the launch)
+    if (s->rr[q1] == s->rr[q]) {
+        if (tid == 0) os[bc * kMaxRanks + q1] = Traits<V>::value((K)prefix);
+        return;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        s_nloc = 0;      // elements <= x_r
+        s_kmin = ~0ull;  // smallest key above x_r's
+    }
+    __syncthreads();
+    {
+        uint32_t cle = 0;
+        unsigned long long kgt = ~0ull;
+        auto look = [&](V x, bool ok) {
+            const unsigned long long key = (unsigned long long)Traits<V>::key(x);
+            if (ok) {
+                if (key <= prefix) ++cle;
+                else kgt = key < kgt ? key : kgt;
+            }
+        };
+        if (local) {
+            for (uint32_t i = tid; i < nloc; i += 1024) look(s_buf[i], true);
+        } else {
+            for (uint32_t base = 0; base < cnt; base += 1024) {
+                const uint32_t i = base + tid;
+                const V x = i < cnt ? L[i] : (V)-1;
+                look(x, tb == kLinAnyBin ? i < cnt : lin_digit(x) == tb);
+            }
+        }
+        cle = wave_sum_u32(cle);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = shfl_u64(kgt, lane ^ o);
+            kgt = a < kgt ? a : kgt;
+        }
+        if (lane == 0) {
+            atomicAdd(&s_nloc, cle);
+            atomicMin(&s_kmin, kgt);
+        }
+    }
+    __syncthreads();
+    // rank_in_list(x_r) = rr[q]: the next one is x_r again if more than rr[q] + 1 elements are <= x_r
+    if (tid == 0) os[bc * kMaxRanks + q1] = Traits<V>::value((K)(s_nloc > s->rr[q1] ? prefix : s_kmin));
 }
 
 struct LinBufs {
@@ -955,7 +1062,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
-                plan.flags);
+                plan.flags, 0);
     UWIE_LAUNCH_CHECK();
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
@@ -963,6 +1070,27 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
         const int rc = launch_restore_planar_hist(src->in, src->kind, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags, nullptr, src->t32);
         if (rc != UWIE_OK) return rc;
     }
+    UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
+    UWIE_LAUNCH_CHECK();
+    UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
+    return run_t<float>(plan, d_planar, 1, s, false, st, plan.flags);
+}
+
+// After launch_restore_rank: scan -> finish on the window lists; flagged planes take the generic sweeps as in select_lin_run.
+int select_rank_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc &src)
+{
+    const int nbc = s.B * 3;
+    RankList ranks;
+    ranks.n = 2 * plan.nq;
+    for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
+    LinState *lin = (LinState *)plan.lin;
+    UWIE_LAUNCH(k_rank_scan, dim3(cdiv(nbc, 64)), dim3(64), 0, st, lin, ranks, (float *)plan.os, plan.flags, plan.cap, nbc);
+    UWIE_LAUNCH_CHECK();
+    UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
+                plan.flags, 1);
+    UWIE_LAUNCH_CHECK();
+    const int rc = launch_restore_planar_hist(src.in, src.kind, src.A, src.t, s, d_planar, nullptr, st, true, plan.flags, nullptr, src.t32);
+    if (rc != UWIE_OK) return rc;
     UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
     UWIE_LAUNCH_CHECK();
     UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
@@ -1038,7 +1166,7 @@ int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStrea
     }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<double>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const double *)lists, plan.cap, (double *)plan.os,
-                plan.flags);
+                plan.flags, 0);
     UWIE_LAUNCH_CHECK();
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
