@@ -40,6 +40,8 @@ KERNEL_BYTES_PER_PX = {
     # the default guided filter is two launches that split the rows of a frame (uwie_guided_plan): main() scales these by
     # the fraction of the rows each covers
     "k_guided_split": 1 + 4 + 8, "k_guided_pipe": 1 + 4 + 8,
+    # round 4: the guided filter with the transmission's first half fused in (reads the u8 frame instead of a float32 t0 plane)
+    "k_guided_split8": 3 + 1 + 8,
     "k_box_rows<SrcGuide>": 1 + 4 + 4 * 8, "k_box_cols<EpiAB>": 4 * 8 + 2 * 8,
     "k_box_rows<SrcPlanes2>": 2 * 8 + 2 * 8, "k_box_cols<EpiQ>": 2 * 8 + 1 + 8, "k_restore": 3 + 8 + 12,
     "k_sel_hist<V>": 2 * 3 * 4, "k_restore_hist_collect": 3 + 8 + 12, "k_restore_hist_lin": 3 + 8 + 12,

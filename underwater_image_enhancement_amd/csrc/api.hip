@@ -65,7 +65,8 @@ const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::
                            {"lin_predict3", &Tuning::lin_predict3}, {"lin_cap", &Tuning::lin_cap},
                            {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
                            {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass},
-                           {"canny_fault_inject", &Tuning::canny_fault_inject}, {"rank_sweep", &Tuning::rank_sweep}};
+                           {"canny_fault_inject", &Tuning::canny_fault_inject}, {"rank_sweep", &Tuning::rank_sweep},
+                           {"gf_fuse", &Tuning::gf_fuse}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only
 {
@@ -234,10 +235,17 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
 {
     const float eps = 1e-6f;  // six_stadigy.py:198,218
     const int k = p->strategy;
-    UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, (float)p->omega, 1e-6f, 1, P.t0, st));
     int t_is_f32 = 0;
     // (the three-digit key sweeps of tuning select_generic instantiate the restore for the float64 plane only: no float32 t there)
-    UWIE_TRY(stage_guided(ctx, P, s, p, st, tune().select_generic ? nullptr : &t_is_f32));
+    const bool want_f32 = p->inter_dtype == UWIE_INTER_F32T && !tune().select_generic && !(s.W & 1);
+    if (!p->gf_exact && p->gf_eps > 0.0 && (p->inter_dtype != UWIE_INTER_FX32) && guided_fused_takes(s, p->gf_ksize)) {
+        // round 4: the transmission's first half (S6:170-174) is evaluated inside the guided filter: no t0 plane
+        UWIE_TRY(launch_guided_fused(P.gray, d_in, kind, P.A, (float)p->omega, 1e-6f, 1, s, p->gf_ksize, p->gf_eps, P.t, st, want_f32));
+        t_is_f32 = want_f32;
+    } else {
+        UWIE_TRY(launch_trans_init(d_in, kind, P.A, s, (float)p->omega, 1e-6f, 1, P.t0, st));
+        UWIE_TRY(stage_guided(ctx, P, s, p, st, tune().select_generic ? nullptr : &t_is_f32));
+    }
     // fused tail: restore writes the planar image into P.F and feeds the selection's first histogram sweep
     SelectPlan plan;
     const double q[4] = {p->L_low, p->L_high, p->wb_percentile, 100 - p->wb_percentile};
@@ -300,8 +308,12 @@ int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_para
                     float *d_out_f32, hipStream_t st, double *d_out_f64 = nullptr)
 {
     UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift));
-    UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, (float)p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
-    UWIE_TRY(stage_guided(ctx, P, s, p, st));
+    if (!p->gf_exact && p->gf_eps > 0.0 && guided_fused_takes(s, p->gf_ksize)) {
+        UWIE_TRY(launch_guided_fused(P.gray, d_in, nullptr, P.A, (float)p->omega, 1e-10f, 0, s, p->gf_ksize, p->gf_eps, P.t, st, false));
+    } else {
+        UWIE_TRY(launch_trans_init(d_in, nullptr, P.A, s, (float)p->omega, 1e-10f, 0, P.t0, st));  // ES:221-225
+        UWIE_TRY(stage_guided(ctx, P, s, p, st));
+    }
     SelectPlan plan;
     const double q[2] = {p->L_low, p->L_high};
     // the recovered image is clipped to [0, 1]: linear first digit, one collecting sweep (select_lin_*64);

@@ -100,6 +100,7 @@ struct Tuning {
     int lin_predict_shift = 0;  // predicted windows moved by this many bins (large: every prediction misses)
     int streams = 1;            // uwie_enhance_u8: sub-batches on this many internal streams (1 .. 4)
     int canny_prepass = 1;      // quadtree: the streaming "any strong pixel?" pass before Canny
+    int gf_fuse = 1;            // ... with t0 computed from the frame's bytes inside it (k_guided_split8; 0: k_trans_init + t0 plane)
     int rank_sweep = 1;         // strategies 1-2: the rank-counting restore sweep (0: the histogram sweep)
     int canny_fault_inject = 0; // tests only: k_canny_gradnms leaves out the root labels (the round-3 defect): uwie_device_status must report it
 };
@@ -113,6 +114,7 @@ struct uwie_ctx {
     bool attr_q_tail = false;   // > 64 KB LDS attributes set on this context's device: k_q_tail,
     bool attr_cast_resolve = false;  // k_cast_resolve (the rounding table of every binade: 70 KB),
     int attr_gf_fast = 0;       // k_guided_fast<TH> (bit TH)
+    int attr_gf_split8 = 0;     // k_guided_split8<15, double / float> (bits 1 / 2)
     uwie::LabTables *d_lab;
     uwie::CastTables *d_cast;
     uwie::Profiler *prof;
@@ -219,6 +221,10 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows =
 // "not taken, nothing written"
 int launch_guided_pipe(const uint8_t *d_gray, const float *d_t0, Shape s, int k, double eps, int ring, double *d_t,
                        int *handled, hipStream_t st, bool out_f32 = false);
+// the same filter with t0 = 1 - omega * min_c(img / (A + eps)) [clipped] computed inside it from the u8 frame (round 4)
+bool guided_fused_takes(Shape s, int k);
+int launch_guided_fused(const uint8_t *d_gray, const uint8_t *d_rgb, const int32_t *d_kind, const float *d_A, float omega,
+                        float norm_eps, int pre_clip, Shape s, int k, double eps, double *d_t, hipStream_t st, bool out_f32);
 
 // k_select.hip
 constexpr int kMaxPct = 4;  // percentiles per call

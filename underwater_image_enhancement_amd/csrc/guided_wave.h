@@ -67,6 +67,7 @@ struct SplitGeom {
     int H, W, y0, band;  // bands of `band` rows (a multiple of the ring period) from row y0, every strip
     int y_end;           // the last band runs to this row (shorter or longer than `band`; whole ring periods unless it is H)
     int xcd_fold;        // fold launch order so that an XCD's workgroups are neighbours (see k_guided_split)
+    int nbands;          // bands per strip (the last one runs to y_end)
 };
 
 // Neighbouring strips share the cache lines their halos overlap in (a strip's rows start at arbitrary bytes).  Workgroups are

@@ -633,9 +633,26 @@ struct SplitCfg {
 // fill up from zero, which IS the direct sum of the first window because the leaving rows are the zeros the ring was
 // cleared to), and band/RC periods of identical steps.  Every step of a period has its ring slot as a compile-time
 // constant: b lives in registers, the LDS address of a is an immediate, and there is no slot arithmetic at all.
-template <int K, bool EDGE, typename TOut>
+// t0 of one pixel from its bytes (FUSE: first half of estimate_transmission, six_stadigy.py:170-174 / enhancement_strategies.py:
+// 221-225, exactly k_trans_init's operations): tab = img / (A + eps) of the 3 x 256 possible bytes (IEEE divisions, made once per
+// workgroup).  This file is compiled with -ffp-contract=fast: the product and the difference are NumPy's two roundings, so they
+// are spelled with the intrinsics that are never contracted.
+__device__ __forceinline__ uint32_t fuse_t0_bits(const float *tab, uint32_t r, uint32_t g, uint32_t b, float omega, int pre_clip)
+{
+    const float dark = fminf(fminf(tab[r], tab[256 + g]), tab[512 + b]);
+    float t = __fsub_rn(1.0f, __fmul_rn(omega, dark));
+    if (pre_clip) t = fminf(fmaxf(t, 0.1f), 1.0f);
+    return __float_as_uint(t);
+}
+
+// FUSE: the raw transmission plane is not read -- t0 is computed from the frame's bytes on the way in (`t0` then points at the
+// u8 RGB frame, tab at the workgroup's LDS table); lane: the wavefront's lane (the 8-wavefront workgroups of k_guided_split8).
+// (Measured and dropped, round 4: the same with the one-wavefront launch shape and the table in GLOBAL memory, six gathers
+// through a buffer resource at the top of a step -- 3.70 ms against 3.46 for the LDS table and 2.83 + 0.71 unfused.)
+template <int K, bool EDGE, typename TOut, bool FUSE = false>
 __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, const float *__restrict__ t0, TOut *__restrict__ tout,
-                                           const SplitGeom &g, const PipeConsts &cs, char *lds, int3 bid)
+                                           const SplitGeom &g, const PipeConsts &cs, char *lds, int3 bid, int lane_in = -1,
+                                           const float *tab = nullptr, float omega = 0.0f, int pre_clip = 0)
 {
     using C = PipeCfg<K>;
     // Any window width (round 3: even ones too).  With the output row of an a/b row r taken as r - Lb (Lb = K - 1 - a rows
@@ -656,16 +673,18 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     constexpr uint32_t stage_base = SplitCfg<K>::STAGE_FIRST ? 0u : (uint32_t)ring_bytes;
     constexpr uint32_t ring_base = SplitCfg<K>::STAGE_FIRST ? 3072u + 2048u : 0u;
     constexpr double K2 = (double)(K * K);
-    const int lane = threadIdx.x;
+    const int lane = lane_in >= 0 ? lane_in : (int)threadIdx.x;
     const int H = g.H, W = g.W;
     const int x_lo = bid.x * NV;
     const int y_lo = g.y0 + bid.y * g.band;
     const int r_lo = y_lo - a;
     const size_t img = (size_t)bid.z * H * W;
     const uint32_t npx = (uint32_t)H * (uint32_t)W;
-    const __amdgpu_buffer_rsrc_t rT = pipe_rsrc(t0 + img, npx * 4u), rG = pipe_rsrc(gray + img, npx),
-                                 rO = pipe_rsrc(tout + img, npx * (uint32_t)sizeof(TOut));
-    const uint32_t pitch_t = (uint32_t)W * 4u, pitch_g = (uint32_t)W, pitch_o = (uint32_t)W * (uint32_t)sizeof(TOut);
+    // FUSE: rT is the RGB frame (3 bytes per column) instead of the float32 t0 plane
+    constexpr uint32_t kTB = FUSE ? 3u : 4u;
+    const __amdgpu_buffer_rsrc_t rT = FUSE ? pipe_rsrc(reinterpret_cast<const uint8_t *>(t0) + img * 3, npx * 3u) : pipe_rsrc(t0 + img, npx * 4u),
+                                 rG = pipe_rsrc(gray + img, npx), rO = pipe_rsrc(tout + img, npx * (uint32_t)sizeof(TOut));
+    const uint32_t pitch_t = (uint32_t)W * kTB, pitch_g = (uint32_t)W, pitch_o = (uint32_t)W * (uint32_t)sizeof(TOut);
 
     // Interior strips (!EDGE): a lane's two slots are adjacent raw columns inside the image: one 8-byte / 2-byte load for
     // both.  EDGE strips (their raw columns run over the left/right image border): reflected columns, one load per slot,
@@ -678,7 +697,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     for (int j = 0; j < 2; ++j) {
         const int sl = 2 * lane + j;
         craw[j] = EDGE ? pipe_reflect(x_lo - 2 * a + sl, W) : x_lo - 2 * a + sl;
-        ofs_t[j] = (uint32_t)craw[j] * 4u;
+        ofs_t[j] = (uint32_t)craw[j] * kTB;
         ofs_g[j] = (uint32_t)craw[j];
         ofs_o[j] = EDGE ? (uint32_t)min(xo0 + j, W - 1) : (uint32_t)min(xo0, W - 2);
         ofs_q[j] = sl < NV && xo0 + j < W ? (uint32_t)(xo0 + j) * (uint32_t)sizeof(TOut) : kNoStore;
@@ -702,6 +721,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         uint32_t tl[2];         // (!RAWREG) leaving raw row
     };
     auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
+    static_assert(!FUSE || RAWREG, "the fused transmission keeps its rows in the register ring (no leaving-row reload)");
     auto load_rows = [&](uint32_t oe_t, uint32_t oe_g, uint32_t ol_t, uint32_t ol_g, uint32_t oo_g, In &in) {
         if constexpr (!RAWREG) {
             if constexpr (!EDGE) {
@@ -720,18 +740,44 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         }
 #endif
         if constexpr (!EDGE) {
-            const u32x2 te = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], oe_t, 0);
+            if constexpr (FUSE) {  // the two pixels' six bytes: a dword (2-byte aligned: the column is even) and a short
+                in.te[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[0], oe_t, 0);
+                in.te[1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rT, ofs_t[0] + 4u, oe_t, 0);
+            } else {
+                const u32x2 te = __builtin_amdgcn_raw_buffer_load_b64(rT, ofs_t[0], oe_t, 0);
+                in.te[0] = te.x; in.te[1] = te.y;
+            }
             in.ge[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], oe_g, 0);
             in.go[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_o[0], oo_g, 0);
-            in.te[0] = te.x; in.te[1] = te.y;
             in.ge[1] = in.go[1] = 0;
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                in.te[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], oe_t, 0);
+                if constexpr (FUSE) {  // one pixel per load set: R | G << 8 | B << 16
+                    const uint32_t r = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[j], oe_t, 0);
+                    const uint32_t gg = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[j] + 1u, oe_t, 0);
+                    const uint32_t bb = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[j] + 2u, oe_t, 0);
+                    in.te[j] = r | (gg << 8) | (bb << 16);
+                } else {
+                    in.te[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[j], oe_t, 0);
+                }
                 in.ge[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[j], oe_g, 0);
                 in.go[j] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_o[j], oo_g, 0);
             }
+        }
+    };
+    // float bits of the entering row's two transmissions (FUSE: from the bytes the loads returned)
+    auto te_bits = [&](const In &in, uint32_t (&tb)[2]) {
+        if constexpr (!FUSE) {
+            tb[0] = in.te[0]; tb[1] = in.te[1];
+        } else if constexpr (!EDGE) {
+            const uint32_t w0 = in.te[0], w1 = in.te[1];
+            tb[0] = fuse_t0_bits(tab, w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, omega, pre_clip);
+            tb[1] = fuse_t0_bits(tab, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u, omega, pre_clip);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                tb[j] = fuse_t0_bits(tab, in.te[j] & 255u, (in.te[j] >> 8) & 255u, (in.te[j] >> 16) & 255u, omega, pre_clip);
         }
     };
 
@@ -747,7 +793,14 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             gq[c] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[c], row * pitch_g, 0);
-            tb[c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0);
+            if constexpr (FUSE) {
+                const uint32_t r = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[c], row * pitch_t, 0);
+                const uint32_t gg = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[c] + 1u, row * pitch_t, 0);
+                const uint32_t bb = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rT, ofs_t[c] + 2u, row * pitch_t, 0);
+                tb[c] = fuse_t0_bits(tab, r, gg, bb, omega, pre_clip);
+            } else {
+                tb[c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[c], row * pitch_t, 0);
+            }
             const double p = (double)__uint_as_float(tb[c]);
             Sg[c] += gq[c];
             Sgg[c] += gq[c] * gq[c];
@@ -808,7 +861,6 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         constexpr bool WARM = decltype(warm_tag)::value;
         constexpr int S = decltype(slot_tag)::value;
         char *ring_p = lds + a_ring + (uint32_t)((S >= AR ? S - AR : 0) * NLp * EB);
-
         // ================= read phase
         double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
         if constexpr (!WARM) window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
@@ -887,7 +939,9 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         V2a[0] += av[0] - la.x; V2a[1] += av[1] - la.y;
         V2b[0] += bv[0] - lb0;  V2b[1] += bv[1] - lb1;
         // A: V1 += raw(entering) - raw(leaving); the entering row takes the leaving row's place in the register ring
-        uint32_t lt[2] = {in.te[0], in.te[1]}, lg = EDGE ? (in.ge[0] | (in.ge[1] << 8)) : in.ge[0];
+        uint32_t tbe[2];
+        te_bits(in, tbe);
+        uint32_t lt[2] = {tbe[0], tbe[1]}, lg = EDGE ? (in.ge[0] | (in.ge[1] << 8)) : in.ge[0];
         if constexpr (RAWREG) raw.template swap_at<S>(lt[0], lt[1], lg);
         else { lt[0] = in.tl[0]; lt[1] = in.tl[1]; }
 #if !SPLIT_RAW_G
@@ -895,7 +949,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 #endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double pe = (double)__uint_as_float(in.te[c]), pl = (double)__uint_as_float(lt[c]);
+            const double pe = (double)__uint_as_float(tbe[c]), pl = (double)__uint_as_float(lt[c]);
             const uint32_t ge = byte_of(in.ge, c), gl = c == 0 ? (lg & 255u) : (lg >> 8);
             Sg[c] += ge - gl;
             Sgg[c] += ge * ge - gl * gl;
@@ -950,7 +1004,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     // warm period: steps r_lo+1 .. r_lo+RC (slots 0 .. RC-1)
     period(std::true_type{});
     // normal periods: the band's rows (the last band stops at the image's last row)
-    const int nper = (((int)bid.y == (int)gridDim.y - 1 ? g.y_end - y_lo : g.band) + RC - 1) / RC;
+    const int nper = (((int)bid.y == g.nbands - 1 ? g.y_end - y_lo : g.band) + RC - 1) / RC;
     for (int p = 0; p < nper; ++p) period(std::false_type{});
 }
 
@@ -981,13 +1035,98 @@ k_guided_split(const uint8_t *__restrict__ gray, const float *__restrict__ t0, T
     else split_body<K, false, TOut>(gray, t0, tout, g, cs, lds, bid);
 }
 
+// ---------------------------------------------------------------- the same strips, eight to a workgroup, t0 computed on the way in
+// Round 4: the raw transmission plane (k_trans_init: 3 B/px read, 4 written, then 4 read here; 0.72 ms at 4K x 64) is not
+// materialised.  t0 of a pixel is a function of its three bytes -- min_c(img_c / (A_c + eps)) through a 3 x 256 table of IEEE
+// quotients -- so a strip's wavefront reads the frame's bytes (6 per lane and row instead of 8) and looks the quotients up.
+// The table is 3 KB: one per wavefront would cost the eighth wavefront of a CU (8 x 19.2 KB of ring and staging lines leave
+// 10 KB), so eight strips share a workgroup and ONE table.  Nothing else is shared: every wavefront keeps its own LDS
+// region and its own pace (one barrier, after the table is filled).  grid (ceil(strips * bands / 8), 1, B), block 512.
+struct FuseT0Args {
+    const uint8_t *rgb;    // [B][H][W][3]
+    const int32_t *kind;   // [B] cast kinds or nullptr
+    const float *A;        // [B][3]
+    float omega, norm_eps;
+    int pre_clip;
+};
+
+template <int K, typename TOut>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_guided_split8(const uint8_t *__restrict__ gray, FuseT0Args fz, TOut *__restrict__ tout, SplitGeom g, PipeConsts cs, int nstrips)
+{
+    extern __shared__ double2 lds_raw[];
+    char *lds = reinterpret_cast<char *>(lds_raw);
+    constexpr int per_wave = SplitCfg<K>::lds_bytes;
+    float *tab = reinterpret_cast<float *>(lds + 8 * per_wave);
+    // (readfirstlane: the compiler has to KNOW that the wavefront index is uniform -- strip, band and every row offset derive
+    // from it, and a row offset it takes for divergent turns each buffer access into a waterfall loop: 803 loops in the first build)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // Launch order folded per XCD as in k_guided_split: the workgroups one XCD receives (every eighth in launch order) are
+    // neighbours -- consecutive groups of strips, band after band, image after image -- behind the same L2.
+    int grp = (int)blockIdx.x, b = (int)blockIdx.z;
+    if (g.xcd_fold) {
+        const uint32_t gx = gridDim.x, n = gx * gridDim.z, lin = blockIdx.x + gx * blockIdx.z;
+        const uint32_t xcd = lin & 7u, idx = lin >> 3, q = n >> 3, r = n & 7u;
+        const uint32_t log = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        grp = (int)(log % gx);
+        b = (int)(log / gx);
+    }
+    {
+        const int kd = fz.kind ? fz.kind[b] : 0;
+        for (int i = threadIdx.x; i < 768; i += 512) {
+            const int c = i >> 8;
+            tab[i] = px_val(i & 255, px_atten(kd, c)) / (fz.A[b * 3 + c] + fz.norm_eps);  // S6:170 / ES:221, as k_trans_init
+        }
+    }
+    __syncthreads();
+    const int item = grp * 8 + wave;
+    if (item >= nstrips * g.nbands) return;  // (wavefront-uniform; no barrier follows)
+    const int3 bid = {item % nstrips, item / nstrips, b};
+    const int x_lo = bid.x * PipeCfg<K>::NV;
+    const bool edge = x_lo - 2 * PipeCfg<K>::a < 0 || x_lo - 2 * PipeCfg<K>::a + kPipeSlots > g.W;  // wave-uniform
+    const float *t0 = reinterpret_cast<const float *>(fz.rgb);
+    if (edge) split_body<K, true, TOut, true>(gray, t0, tout, g, cs, lds + wave * per_wave, bid, lane, tab, fz.omega, fz.pre_clip);
+    else split_body<K, false, TOut, true>(gray, t0, tout, g, cs, lds + wave * per_wave, bid, lane, tab, fz.omega, fz.pre_clip);
+}
+
+template <int K, typename TOut>
+int launch_split8(const uint8_t *d_gray, const FuseT0Args &fz, Shape s, const PipeConsts &cs, TOut *d_t, int y0, int band, int nbands,
+                  int y_end, hipStream_t st)
+{
+    using C = PipeCfg<K>;
+    constexpr int lds = 8 * SplitCfg<K>::lds_bytes + 768 * 4;
+    static_assert(lds <= 160 * 1024, "eight strips and the table have to fit one CU");
+#ifndef UWIE_SPLIT8_FOLD
+#define UWIE_SPLIT8_FOLD 1
+#endif
+    SplitGeom g{s.H, s.W, y0, band, y_end, UWIE_SPLIT8_FOLD, nbands};
+    const int nstrips = cdiv(s.W, C::NV);
+    uwie_ctx *ctx = current_ctx();
+    const int bit = std::is_same<TOut, double>::value ? 1 : 2;
+    if (ctx && !(ctx->attr_gf_split8 & bit)) {  // more than 64 KB of dynamic LDS: once per context and instantiation
+        UWIE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_guided_split8<K, TOut>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ctx->attr_gf_split8 |= bit;
+    }
+    {
+        UWIE_PROF("k_guided_split8", st);
+        hipLaunchKernelGGL((k_guided_split8<K, TOut>), dim3(cdiv((long long)nstrips * nbands, 8), 1, s.B), dim3(512), (size_t)lds, st, d_gray,
+                           fz, d_t, g, cs, nstrips);
+    }
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
 template <int K, typename TOut>
 int launch_split(const uint8_t *d_gray, const float *d_t0, Shape s, const PipeConsts &cs, TOut *d_t, int y0, int band, int nbands,
                  int y_end, hipStream_t st)
 {
     using C = PipeCfg<K>;
     constexpr int lds = SplitCfg<K>::lds_bytes;
-    SplitGeom g{s.H, s.W, y0, band, y_end, 1};  // launch order folded per XCD (measured: reads 6.50 -> 3.6 GB per launch)
+#ifndef UWIE_SPLIT_FOLD
+#define UWIE_SPLIT_FOLD 1
+#endif
+    SplitGeom g{s.H, s.W, y0, band, y_end, UWIE_SPLIT_FOLD, nbands};  // launch order folded per XCD (measured: reads 6.50 -> 3.6 GB per launch)
     const int nstrips = cdiv(s.W, C::NV);
     {
         UWIE_PROF("k_guided_split", st);
@@ -1073,6 +1212,32 @@ bool guided_split_plan(Shape s, int k, int *iy0, int *band, int *nb, int *rows)
     }
     // small jobs (fewer long bands than half the chip holds): the general kernel cuts shorter bands
     return forced || strips * n >= 1024;
+}
+
+// The guided filter with the transmission's first half fused in (k_guided_split8): window 15, a frame the split kernel takes
+// whole, tuning gf_pipe / gf_split / gf_fuse on.  false = the caller materialises t0 (launch_trans_init) as before.
+bool guided_fused_takes(Shape s, int k)
+{
+    if (k != 15 || !tune().gf_pipe || !tune().gf_fuse) return false;
+    int iy0, band, nb, rows;
+    return guided_split_plan(s, k, &iy0, &band, &nb, &rows) && rows == s.H;
+}
+
+int launch_guided_fused(const uint8_t *d_gray, const uint8_t *d_rgb, const int32_t *d_kind, const float *d_A, float omega,
+                        float norm_eps, int pre_clip, Shape s, int k, double eps, double *d_t, hipStream_t st, bool out_f32)
+{
+    UWIE_REQUIRE(guided_fused_takes(s, k) && eps > 0.0, "guided_fused: not a job for the fused kernel");
+    const double K2 = (double)k * k, scale = 1.0 / K2;
+    PipeConsts cs{};
+    cs.Ek = 255.0 * K2 * K2 * eps;
+    cs.kaI = scale / 255.0;
+    cs.kb = scale;
+    cs.b0 = 0.0;
+    int iy0, band, nb, rows;
+    guided_split_plan(s, k, &iy0, &band, &nb, &rows);
+    const FuseT0Args fz{d_rgb, d_kind, d_A, omega, norm_eps, pre_clip};
+    if (out_f32) return launch_split8<15, float>(d_gray, fz, s, cs, reinterpret_cast<float *>(d_t), iy0, band, nb, s.H, st);
+    return launch_split8<15, double>(d_gray, fz, s, cs, d_t, iy0, band, nb, s.H, st);
 }
 
 // ring: 0 = float64 (split ring where guided_split_plan takes the job), 1 = fixed-point int32 (requires 0.1 <= t0 <= 1:
