@@ -327,6 +327,77 @@ def main_scatter(args, uw, _lib, torch, world, rank, local, rehearsal):
         dist.destroy_process_group()
 
 
+def main_stream(args, uw, _lib, torch, world, rank, local, rehearsal):
+    """BASELINE.json configs[4] (SURVEY 8e "for C5 skip the root hop"): every rank owns `batch` frames in PINNED host memory and
+    pulls them through its own GPU in chunks -- upload of chunk i+1, enhancement of chunk i and download of chunk i-1 overlap on
+    three HIP streams (StreamEnhancer) -- back into pinned host memory.  No rank talks to another on the data path; value = all
+    ranks' frames / the slowest rank's time, PCIe included.  --inter f32t selects the reduced-precision transmission
+    (uwie_params.inter_dtype = UWIE_INTER_F32T; DESIGN.md section 4 has the stated tolerance and why it is not fp16)."""
+    import torch.distributed as dist
+
+    dev = uw.get_device(local)
+    H, W, B, chunk = args.height, args.width, args.batch, max(1, min(args.chunk, args.batch))
+    over = {"inter_dtype": _lib.INTER_F32T} if args.inter == "f32t" else {}
+    host = torch.empty((B, H, W, 3), dtype=torch.uint8, pin_memory=True)
+    for b0 in range(0, B, chunk):  # (synthesised on the device chunk by chunk: the frames never have to fit HBM at once)
+        n = min(chunk, B - b0)
+        host[b0:b0 + n].copy_(synth_frames(args.dist, n, H, W, dev.torch_device, seed=5000 + 100 * rank + b0))
+    torch.cuda.synchronize()
+    se = uw.StreamEnhancer(H, W, chunk, depth=3, strategy=args.strategy, device=local, **over)
+    sink = torch.empty((B, H, W, 3), dtype=torch.uint8, pin_memory=True)
+
+    def step():
+        done = 0
+        for i, b0 in enumerate(range(0, B, chunk)):
+            if len(se._pending) == se.depth - 1:
+                r = se.result()
+                sink[done:done + r.shape[0]].copy_(r)  # the consumer's copy out of the ring (host to host)
+                done += r.shape[0]
+            se.submit_slot(i, src=host[b0:b0 + min(chunk, B - b0)])
+        while se._pending:
+            r = se.result()
+            sink[done:done + r.shape[0]].copy_(r)
+            done += r.shape[0]
+        assert done == B
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev.torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    if rank == 0:
+        check = None
+        if not args.no_cpu_baseline:  # the first frame against a direct device call on the same bytes (the ring changes nothing)
+            direct = uw.enhance(host[:1].numpy(), strategy=args.strategy, device=local, **over)
+            check = int((direct.astype(int) - sink[:1].numpy().astype(int)).__abs__().max())
+        print(json.dumps({
+            "metric": "megapixels/sec enhanced", "value": round(world * B * H * W * args.steps / elapsed / 1e6, 2),
+            "unit": "megapixels/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32/f32" if args.inter == "f32t" else "f32/f64", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} RGB u8 ({args.dist}) stream: {B} frames per GPU from pinned host memory in chunks of "
+                                   f"{chunk}, upload / strategy{args.strategy} + cast correction / download overlapped on three streams, "
+                                   f"results back in pinned host memory (PCIe-inclusive; BASELINE.json configs[4]; intermediates "
+                                   f"{args.inter}{'; gloo rehearsal, every rank on GPU 0' if rehearsal else ''})",
+                       "frames_per_gpu": B, "chunk": chunk, "height": H, "width": W, "parallelism": f"independent streams x{world}"},
+            "stream_vs_direct_max_lsb": check}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,9 +409,13 @@ def main():
     ap.add_argument("--strategy", type=int, default=2)
     ap.add_argument("--dist", choices=("underwater", "uniform", "hazy"), default="underwater",
                     help="synthetic input distribution (SURVEY.md section 8d); the headline number uses underwater")
-    ap.add_argument("--mode", choices=("local", "scatter"), default="local",
+    ap.add_argument("--mode", choices=("local", "scatter", "stream"), default="local",
                     help="local: every rank enhances frames it already holds (headline, weak scaling).  scatter: rank 0 holds the "
-                         "whole batch in HBM, each step = scatter over RCCL -> enhance -> gather (BASELINE.json configs[3])")
+                         "whole batch in HBM, each step = scatter over RCCL -> enhance -> gather (BASELINE.json configs[3]).  stream: "
+                         "every rank streams its own frames from pinned host memory through its GPU and back (configs[4])")
+    ap.add_argument("--chunk", type=int, default=8, help="--mode stream: frames per upload / enhance / download chunk")
+    ap.add_argument("--inter", choices=("f64", "f32t"), default="f64",
+                    help="--mode stream: number format of the refined transmission (uwie_params.inter_dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel times of the recorded warm-up step to stderr")
     ap.add_argument("--no-extras", action="store_true", help="skip the other input distributions and the 1080p batch=1 case")
@@ -377,6 +452,8 @@ def main():
                  f"{args.gpus} (or without a launcher: bench.py starts the ranks itself)")
     if args.mode == "scatter":
         return main_scatter(args, uw, _lib, torch, world, rank, local, rehearsal)
+    if args.mode == "stream":
+        return main_stream(args, uw, _lib, torch, world, rank, local, rehearsal)
 
     dev = uw.get_device(local)
     H, W, B = args.height, args.width, args.batch

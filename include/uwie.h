@@ -76,7 +76,14 @@ typedef struct uwie_params {
     int32_t apply_gamma;   /* 0/1 (ES `apply_gamma`; S6 strategies 1,4,5,6 always 1)             */
     int32_t gf_exact;      /* guided filter: 1 = reproduce cv2.boxFilter's float64 running-sum order bit for
                               bit (6 materialised planes); 0 (default) = fused single-kernel float64 filter,
-                              same window/border, free summation order: |t - t_exact| <= 1e-11            */
+                              same window/border, free summation order: |t - t_exact| <= 1e-11 (observed 7e-15).
+                              What that means for the u8 OUTPUT of gf_exact = 0: the same bytes as gf_exact = 1 except
+                              where the exact value of a pixel sits on a truncation boundary ahead of CLAHE, so that the
+                              last bit of t decides its byte -- about one pixel in 1e9 bytes (two in a 25 440-case soak,
+                              profiles/r03_soak.txt; tests/test_gpu_fuzz.py keeps one such frame) -- and that pixel then
+                              differs by up to CLAHE's local slope (<= clip_limit) times gamma's slope: 2 - 3 LSB seen,
+                              1 LSB without CLAHE.  gf_exact = 1 has no such pixel; it costs ~4x the filter's time.
+                              The DICT surface's float64 image differs in its last bits (<= 1e-11) under gf_exact = 0. */
     int32_t inter_dtype;   /* number format of the guided filter's a/b intermediates (S6:39-43) when gf_exact = 0:
                               UWIE_INTER_F64 (default) float64 like the reference; UWIE_INTER_FX32 32-bit fixed
                               point (BASELINE.json configs[4] "reduced-precision intermediates": a and b are rounded
@@ -130,13 +137,20 @@ int uwie_profile_row(uwie_ctx *ctx, int i, const char **name, double *total_ms, 
 /* Fill `p` with the reference defaults for (surface, strategy). */
 int uwie_params_init(uwie_params *p, int surface, int strategy);
 
-/* Route selectors of a context: which of several equivalent routes a stage takes where uwie_params has no say (results are
- * the same bytes on every route; the parity tests force the fallback routes this way, profiles/ scripts compare them).
- * Names (default): gf_pipe (1), gf_split (1), gf_bands (0 = chosen from the job), select_generic (0), restore_store (0),
- * lin_predict3 (0), lin_cap (0 = default), lin_no_predict (0), lin_predict_shift (0), q_hist (1: quadtree levels decided
- * from byte histograms where the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used), streams (1; 2 .. 4 = sub-batches on
- * internal streams), canny_prepass (1).  An environment variable UWIE_<NAME> sets the initial value; it is read once, in
- * uwie_create -- no entry point reads the environment.  Unknown names are an error. */
+/* Route selectors of a context: which of several equivalent routes a stage takes where uwie_params has no say (the parity
+ * tests force the fallback routes this way, profiles/ scripts compare them).  Two classes:
+ *   SAME BYTES on every setting -- the selection, storage and quadtree routes: select_generic (0), restore_store (0),
+ *     lin_predict3 (0), lin_cap (0 = default), lin_no_predict (0), lin_predict_shift (0), rank_sweep (1: strategies 1-2 count
+ *     ranks against the predicted windows; 0: the histogram sweep), q_hist (1: quadtree levels decided from byte histograms where
+ *     the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used), canny_prepass (1),
+ *     streams (1; 2 .. 4 = sub-batches on internal streams), gf_fuse (1: the transmission's first half is evaluated inside the
+ *     guided filter for window 15, same float32 operations; 0: k_trans_init writes a t0 plane first);
+ *   SAME TRANSMISSION TO 1e-11, hence the u8 contract of uwie_params.gf_exact = 0 -- which fused guided-filter kernel runs:
+ *     gf_pipe (1), gf_split (1), gf_bands (0 = chosen from the job).  They sum the same windows in different orders.
+ *     (UWIE_INTER_F32T needs the wavefront kernels: with gf_pipe = 0 it keeps float64.)
+ *   canny_fault_inject (0) is for tests/test_gpu_robustness.py only (it breaks an invariant on purpose; see uwie_device_status).
+ * An environment variable UWIE_<NAME> sets the initial value; it is read once, in uwie_create -- no entry point reads the
+ * environment.  Unknown names are an error. */
 int uwie_set_tuning(uwie_ctx *ctx, const char *name, int value);
 int uwie_get_tuning(uwie_ctx *ctx, const char *name, int *value);
 
@@ -231,6 +245,22 @@ int uwie_extract_features_u8(uwie_ctx *ctx, const uint8_t *d_in, float *d_featur
 int uwie_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, int batch, int H, int W, int gray_shift,
                         const double *weights8, double *d_scores, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The labelling loop of main.py:118-146 for a batch: every parameter set ps[0 .. n-1] (Config.STRATEGIES, config.py:28-75:
+ * five DICT sets; SIX sets are accepted too) is applied to the frames, QualityAssessment.comprehensive_assessment
+ * (quality_assessment.py:215-286) scores each result, and the best one per frame -- the FIRST maximum of the weighted total in
+ * the sets' order, like max(strategy_scores, key=strategy_scores.get) (main.py:145) -- is selected, all on the device.
+ * Consecutive DICT dehazing sets share one atmospheric-light quadtree (ES:353,379,425 evaluate the same function of the frame).
+ *   d_scores [n][batch][9] float64: eight scores + weighted total per (set, frame); weights8 as in uwie_quality_scores;
+ *   d_best   [batch] int32: index of the winning set;  d_best_u8 (optional) [batch][H][W][3]: its (y * 255).astype(uint8);
+ *   d_all_u8 (optional) [n][batch][H][W][3]: every set's output (NULL: kept in the workspace only).
+ * Workspace: uwie_workspace_bytes_select(batch, H, W, ps, n, d_all_u8 != NULL).
+ */
+size_t uwie_workspace_bytes_select(int batch, int H, int W, const uwie_params *ps, int n, int with_outputs);
+int uwie_select_best_u8(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int W, const uwie_params *ps, int n,
+                        const double *weights8, uint8_t *d_best_u8, int32_t *d_best, double *d_scores, uint8_t *d_all_u8,
+                        void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------- per-stage entry points (parity tests, composition) ---------------- */
 
 /* detect_image_type (S6:292-302): NumPy's sequential float32 channel means and the 3-way kind. */
@@ -269,7 +299,8 @@ int uwie_guided_filter(uwie_ctx *ctx, const uint8_t *d_gray, const float *d_t0, 
  * kernel reflects row indices at the top and bottom borders itself).  ksize 10 / 20 (non-symmetric window): the whole
  * ring periods between row ksize and row H - (ksize - 2); the rows above and below go to the general kernel
  * (k_guided_pipe) in a second launch.  0 rows = the general kernel alone (small jobs, odd widths, other windows).
- * For benchmarks that price each kernel by the pixels it covers. */
+ * For benchmarks that price each kernel by the pixels it covers.  The function has no context: it answers for the DEFAULT
+ * tuning (gf_pipe = gf_split = 1, gf_bands = 0); a context with other settings runs a different plan. */
 int uwie_guided_plan(int batch, int H, int W, int ksize, int *split_row0, int *split_rows);
 
 /* restore_image (S6:183-188): float32 [batch][H][W][3]. */

@@ -83,6 +83,34 @@ def test_scatter_compute_gather_world2(tmp_path, n_frames):
     assert result.read_text() == "ok"
 
 
+def _gather_first_worker(rank, world, port, n_frames, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n_frames, rank, world)
+        local = torch.full((hi - lo, 6, 5, 3), 10 + rank, dtype=torch.uint8)
+        back = gather_frames(local, n_frames, dst=0)  # the FIRST communication on the group; some shards are empty
+        if rank == 0:
+            want = torch.cat([torch.full((shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0], 6, 5, 3), 10 + r,
+                                         dtype=torch.uint8) for r in range(world)])
+            assert torch.equal(back, want)
+            with open(result_path, "w") as f:
+                f.write("ok")
+        else:
+            assert back is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_as_the_first_communication_with_empty_shards(tmp_path):
+    """gather_frames' grouped point-to-point skips ranks whose shard is empty; as the first communication on a
+    group that is undefined under NCCL / RCCL, so it opens with a collective of its own.  World 3, two frames: rank 2 has none."""
+    result = tmp_path / "result.txt"
+    mp.spawn(_gather_first_worker, args=(3, _free_port(), 2, str(result)), nprocs=3, join=True)
+    assert result.read_text() == "ok"
+
+
 # ------------------------------------------------------------------ bench.py launch behaviour (no GPU needed)
 def _load_bench():
     import importlib.util

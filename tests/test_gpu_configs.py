@@ -199,3 +199,28 @@ def test_24mp_still_runs_and_matches_the_oracle_quadtree(uw, orc):
     # size-independent property: the frame inside a batch of two equals the single call
     pair = np.stack([u8, u8[::-1].copy()])
     assert np.array_equal(uw.enhance(pair)[0], out)
+
+
+def test_bench_stream_mode_two_ranks_rehearsal():
+    """BASELINE.json configs[4] control flow at N > 1: `bench.py --mode stream --gpus 2` starts two ranks
+    itself; each streams its own pinned shard through its own StreamEnhancer (three HIP streams) and the elapsed times meet in a
+    MAX reduction.  One-GPU box: UWIE_BENCH_REHEARSAL puts both ranks on GPU 0 with gloo for the reduction -- a rehearsal of the
+    control flow, not a measurement (RCCL refuses two ranks on one device).  The line must carry both ranks' frames and a stream
+    result identical to a direct call; --inter f32t runs the reduced-precision transmission through the same path."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UWIE_BENCH_REHEARSAL="1")
+    for inter in ("f64", "f32t"):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--mode", "stream", "--gpus", "2", "--height", "256", "--width", "320",
+               "--batch", "6", "--chunk", "4", "--steps", "1", "--warmup", "1", "--inter", inter]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 6 and d["config"]["chunk"] == 4
+        assert d["stream_vs_direct_max_lsb"] == 0 and d["value"] > 0 and "configs[4]" in d["config"]["workload"]

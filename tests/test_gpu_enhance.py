@@ -497,3 +497,43 @@ def test_general_float_images_on_both_surfaces(uw, orc):
     assert np.array_equal(uw.color_correction(g, "greenish"), orc.correct_cast(g, "greenish"))
     with pytest.raises(uw.UnsupportedInputError):
         uw.SixStrategies.strategy2_medium_dehazing(x64)  # six_stadigy.py works on float32 frames
+
+
+def test_select_best_equals_the_labelling_loop_of_main_py(uw, orc):
+    """main.py:118-146 -- the five Config.STRATEGIES through apply_strategy, comprehensive_assessment with
+    Config.QUALITY_WEIGHTS on each result, the first maximum wins -- as ONE device call (uwie_select_best_u8; the three
+    dehazing strategies share one quadtree) against the same loop through the oracle: every strategy's bytes (<= 1 LSB where
+    gamma's pow is involved, identical otherwise), every total within the quality scores' 2e-3, and the same winner wherever
+    the oracle's two best totals are further apart than that."""
+    from test_gpu_configs import underwater
+
+    rng = np.random.default_rng(118)
+    frames = np.stack([underwater(rng, 240, 320, (0.45, 0.85, 0.80)), underwater(rng, 240, 320, (0.45, 0.75, 0.90)),
+                       rng.integers(0, 256, (240, 320, 3), dtype=np.uint8),
+                       np.floor(255 * (rng.random((240, 320, 3)) * 0.7 + 0.15)).astype(np.uint8)])
+    names, images, scores, every = uw.select_best(frames, return_all=True)
+    keys = list(uw.CONFIG_STRATEGIES)
+    assert list(every) == [uw.CONFIG_STRATEGIES[k]["name"] for k in keys] and images.shape == frames.shape
+    for b, u8 in enumerate(frames):
+        x = orc.normalise_u8(u8)  # main.py:108
+        want_scores, want_imgs = {}, {}
+        for k in keys:
+            params = {kk: v for kk, v in uw.CONFIG_STRATEGIES[k].items() if kk != "name"}
+            enhanced = orc.DictStrategyOracle.run(x, k, params)
+            total, _ = orc.quality_assessment(enhanced, weights=uw.CONFIG_QUALITY_WEIGHTS)
+            name = uw.CONFIG_STRATEGIES[k]["name"]
+            want_scores[name] = float(total)
+            want_imgs[name] = (enhanced * 255).astype(np.uint8)  # main.py:155
+            d = np.abs(every[name][b].astype(int) - want_imgs[name].astype(int))
+            assert d.max() <= (1 if params.get("apply_gamma") else 0), (b, name, int(d.max()))
+            assert abs(scores[b][name] - want_scores[name]) <= 2e-3 + 0.05 * int(d.max() > 0), (b, name, scores[b][name], want_scores[name])
+        ranked = sorted(want_scores.values(), reverse=True)
+        want_best = max(want_scores, key=want_scores.get)  # main.py:145
+        if ranked[0] - ranked[1] > 0.2:
+            assert names[b] == want_best, (b, names[b], want_best, want_scores)
+        assert np.array_equal(images[b], every[names[b]][b])
+    # a single frame, a subset of the strategies, custom weights: same protocol
+    sub = {k: uw.CONFIG_STRATEGIES[k] for k in ("clahe_enhancement", "light_enhancement")}
+    name1, img1, sc1 = uw.select_best(frames[0], strategies=sub, weights={"contrast": 1.0})
+    assert name1 in ("CLAHEEnhancement", "LightEnhancement") and img1.shape == frames[0].shape and set(sc1) == {"CLAHEEnhancement", "LightEnhancement"}
+    assert np.array_equal(img1, every[name1][0]) and name1 == max(sc1, key=sc1.get)

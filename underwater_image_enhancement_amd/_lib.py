@@ -78,6 +78,8 @@ SIGNATURES = {
     "uwie_enhance_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_u8_f64": [_VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
     "uwie_enhance_all_u8": [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _SZ, _VP],
+    "uwie_workspace_bytes_select": [_I, _I, _I, _VP, _I, _I],
+    "uwie_select_best_u8": [_VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _VP],
     "uwie_diff_enhance_f32": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _SZ, _VP],
     "uwie_extract_features_u8": [_VP, _VP, _VP, _I, _I, _I, _VP, _SZ, _VP],
     "uwie_quality_scores": [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _SZ, _VP],
@@ -106,6 +108,7 @@ _RESTYPES = {
     "uwie_workspace_bytes": ctypes.c_size_t,
     "uwie_workspace_bytes_all": ctypes.c_size_t,
     "uwie_workspace_bytes_float": ctypes.c_size_t,
+    "uwie_workspace_bytes_select": ctypes.c_size_t,
 }
 
 _lib = None

@@ -284,6 +284,69 @@ def quality_scores(frames_u8, frames_f32=None, weights=None, device: int | None 
     return _finish(dev.quality_scores(batch, f32, w), was_numpy, single)
 
 
+# config.py:28-75 (Config.STRATEGIES) and :77-84 (Config.QUALITY_WEIGHTS): the parameter sets and weights main.py labels with
+CONFIG_STRATEGIES = {
+    "strong_dehazing": {"name": "StrongDehazing", "omega": 0.5, "guided_radius": 15, "L_low": 10, "L_high": 95, "gamma": 1.2,
+                        "apply_gamma": True},
+    "medium_dehazing": {"name": "MediumDehazing", "omega": 0.6, "guided_radius": 20, "L_low": 15, "L_high": 92, "apply_gamma": True},
+    "light_enhancement": {"name": "LightEnhancement", "omega": 0.4, "guided_radius": 10, "L_low": 15, "L_high": 95,
+                          "apply_gamma": False},
+    "clahe_enhancement": {"name": "CLAHEEnhancement", "clip_limit": 2.0, "tile_grid_size": (8, 8), "apply_gamma": False},
+    "histogram_equalization": {"name": "HistogramEqualization", "L_low": 10, "L_high": 95},
+}
+CONFIG_QUALITY_WEIGHTS = {"contrast": 0.25, "sharpness": 0.20, "entropy": 0.15, "saturation": 0.15, "brightness": 0.15,
+                          "edge_density": 0.10}
+
+
+def _dict_params(dev, name, params):
+    """uwie_params of apply_strategy(img, name, params) (ES:350-474: the keys a strategy reads, its in-code defaults otherwise)."""
+    over = {}
+    for key, field in (("omega", "omega"), ("guided_radius", "gf_ksize"), ("L_low", "L_low"), ("L_high", "L_high"),
+                       ("clip_limit", "clip_limit"), ("gamma", "gamma")):
+        if key in params:
+            over[field] = params[key]
+    if "tile_grid_size" in params:
+        over["tiles_x"], over["tiles_y"] = (int(v) for v in params["tile_grid_size"])
+    over["apply_gamma"] = int(bool(params.get("apply_gamma", False)))
+    return dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], **over)
+
+
+def select_best(frames, strategies=None, weights=None, device: int | None = None, return_all: bool = False):
+    """The labelling loop of ``SelfSupervisedSystem.build_dataset`` (main.py:118-146) for one frame or a batch, in ONE device
+    call: every entry of ``strategies`` (default ``Config.STRATEGIES``, config.py:28-75: ``{key: {'name': ..., params}}``) goes
+    through ``apply_strategy``, ``comprehensive_assessment`` with ``weights`` (default ``Config.QUALITY_WEIGHTS``) scores each
+    result, and the first maximum wins (main.py:145).  The three dehazing strategies share one atmospheric-light quadtree.
+
+    ``frames``: uint8 ``[H,W,3]`` / ``[B,H,W,3]`` (main.py:108 makes ``u8.astype(float32) / 255`` of exactly these).
+    Returns ``(best_names, best_images, scores)``: the winner's ``'name'`` per frame (a string for a single frame), its
+    ``(enhanced * 255).astype(uint8)`` image (main.py:154-155 writes that), and ``scores[frame][name] = total``; with
+    ``return_all`` a fourth value ``{name: uint8 batch}`` holds every strategy's output.  A strategy the device cannot
+    run fails the call: fall back to ``EnhancementStrategies.apply_strategy`` + ``QualityAssessment`` per strategy, whose
+    ``try`` blocks give a failing strategy the score 0.0 like main.py:139-142.
+    """
+    strategies = CONFIG_STRATEGIES if strategies is None else strategies
+    weights = CONFIG_QUALITY_WEIGHTS if weights is None else weights
+    dev = get_device(device)
+    batch, was_numpy, single = _as_batch_u8(frames, dev)
+    keys = list(strategies)
+    for k in keys:
+        if k not in _lib.DICT_STRATEGIES:
+            raise ValueError(f"未知策略: {k}")
+    plist = [_dict_params(dev, k, strategies[k]) for k in keys]
+    names = [strategies[k].get("name", k) for k in keys]
+    w = [weights.get(k, 0) for k in QUALITY_KEYS]
+    best, img, scores, every = dev.select_best_u8(batch, plist, w, want_all=return_all)
+    best_h = best.cpu().tolist()
+    tot = scores[:, :, 8].cpu().numpy()
+    dev.check_status()
+    best_names = [names[i] for i in best_h]
+    table = [{names[k]: float(tot[k, b]) for k in range(len(keys))} for b in range(len(best_h))]
+    out = (best_names[0] if single else best_names, _finish(img, was_numpy, single), table[0] if single else table)
+    if return_all:
+        out = out + ({names[k]: _finish(every[k], was_numpy, single) for k in range(len(keys))},)
+    return out
+
+
 def extract_all_features(img, device: int | None = None):
     """``vgg_16_UIE.extract_all_features(img)`` (vgg_16_UIE.py:435-466) for a uint8 RGB frame ``[H,W,3]`` (returns the
     reference's ``(79,)`` float32 vector) or a batch ``[B,H,W,3]`` (returns ``(B, 79)``).  Float inputs of the reference
@@ -447,15 +510,7 @@ class EnhancementStrategies:
                     u8 = cand
             except UnsupportedInputError:
                 pass
-        over = {}
-        for key, field in (("omega", "omega"), ("guided_radius", "gf_ksize"), ("L_low", "L_low"), ("L_high", "L_high"),
-                           ("clip_limit", "clip_limit"), ("gamma", "gamma")):
-            if key in params:
-                over[field] = params[key]
-        if "tile_grid_size" in params:
-            over["tiles_x"], over["tiles_y"] = (int(v) for v in params["tile_grid_size"])
-        over["apply_gamma"] = int(bool(params.get("apply_gamma", False)))
-        p = dev.params(_lib.SURFACE_DICT, _lib.DICT_STRATEGIES[name], **over)
+        p = _dict_params(dev, name, params)
         # float64 like the reference (ES:247,307,345): a caller's (enhanced * 255).astype(np.uint8) (main.py:155) then
         # truncates the same values as with the reference
         if u8 is not None:

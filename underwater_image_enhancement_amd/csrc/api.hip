@@ -186,7 +186,7 @@ int stage_guided(uwie_ctx *ctx, const Pipe &P, Shape s, const uwie_params *p, hi
 {
     int handled = 0;
     if (t_is_f32) *t_is_f32 = 0;
-    if (t_is_f32 && p->inter_dtype == UWIE_INTER_F32T && !p->gf_exact && p->surface == UWIE_SURFACE_SIX) {
+    if (t_is_f32 && p->inter_dtype == UWIE_INTER_F32T && !p->gf_exact && p->surface == UWIE_SURFACE_SIX && tune().gf_pipe) {
         UWIE_TRY(launch_guided_pipe(P.gray, P.t0, s, p->gf_ksize, p->gf_eps, 0, P.t, &handled, st, true));
         if (handled) {
             *t_is_f32 = 1;
@@ -304,10 +304,13 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
 }
 
 // enhancement_strategies.py apply_strong/medium/light (ES:350-444) on the uncorrected frame
+// have_airlight: P.gray and P.A already hold the gray plane and the atmospheric light of these frames (they depend on the
+// frame, min_size and gray_shift only: ES:353,379,425 all call estimate_atmospheric_light(img) -- uwie_select_best_u8 shares them)
 int run_dict_dehaze(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, uint8_t *d_out_u8,
-                    float *d_out_f32, hipStream_t st, double *d_out_f64 = nullptr)
+                    float *d_out_f32, hipStream_t st, double *d_out_f64 = nullptr, bool have_airlight = false)
 {
-    UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift));
+    if (!have_airlight)
+        UWIE_TRY(launch_airlight(ctx, d_in, nullptr, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift));
     if (!p->gf_exact && p->gf_eps > 0.0 && guided_fused_takes(s, p->gf_ksize)) {
         UWIE_TRY(launch_guided_fused(P.gray, d_in, nullptr, P.A, (float)p->omega, 1e-10f, 0, s, p->gf_ksize, p->gf_eps, P.t, st, false));
     } else {
@@ -917,6 +920,82 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
         else UWIE_TRY(launch_code_strategy(ctx, d_in, kind, s, &P6[k], out, nullptr, P.scratch, st));
     }
     return UWIE_OK;
+}
+
+// ---- main.py:118-146: every strategy of Config.STRATEGIES on the frame, comprehensive_assessment of each result, the best one
+namespace {
+struct SelectBufs {
+    void *pipe;
+    size_t pipe_bytes;
+    uint8_t *all;
+    float *f32;
+    void *qa;
+};
+SelectBufs carve_select(Carver &c, Shape s, const uwie_params *ps, int n, bool own_all)
+{
+    SelectBufs b{};
+    for (int k = 0; k < n; ++k) {
+        Carver ck(nullptr);
+        carve_pipe(ck, s, &ps[k]);
+        if (ck.total() > b.pipe_bytes) b.pipe_bytes = ck.total();
+    }
+    b.pipe = c.take<char>(b.pipe_bytes);
+    b.all = own_all ? c.take<uint8_t>((size_t)n * s.B * s.npx() * 3) : nullptr;
+    b.f32 = c.take<float>((size_t)s.B * s.npx() * 3);
+    b.qa = c.take<char>(quality_ws_bytes(s));
+    return b;
+}
+}  // namespace
+
+size_t uwie_workspace_bytes_select(int batch, int H, int W, const uwie_params *ps, int n, int with_outputs)
+{
+    if (!shape_ok(batch, H, W) || !ps || n < 1 || n > 16) return 0;
+    Carver c(nullptr);
+    carve_select(c, Shape{batch, H, W}, ps, n, !with_outputs);
+    return c.total();
+}
+
+int uwie_select_best_u8(uwie_ctx *ctx, const uint8_t *d_in, int batch, int H, int W, const uwie_params *ps, int n,
+                        const double *weights8, uint8_t *d_best_u8, int32_t *d_best, double *d_scores, uint8_t *d_all_u8,
+                        void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    UWIE_REQUIRE(ctx && d_in && ps && d_best && d_scores, "select_best: NULL pointer");
+    UWIE_SCOPE(ctx);
+    UWIE_CHECK_SHAPE(batch, H, W);
+    UWIE_REQUIRE(n >= 1 && n <= 16, "select_best: 1 .. 16 strategies");
+    for (int k = 0; k < n; ++k) UWIE_TRY(check_params(&ps[k]));
+    static const double kDefault[8] = {0.20, 0.20, 0.15, 0.15, 0.10, 0.10, 0.05, 0.05};  // quality_assessment.py:229-238
+    const Shape s{batch, H, W};
+    Carver c(d_workspace);
+    SelectBufs sb = carve_select(c, s, ps, n, d_all_u8 == nullptr);
+    UWIE_CHECK_WS(c.total());
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *all = d_all_u8 ? d_all_u8 : sb.all;
+    const size_t frame_set = (size_t)batch * H * W * 3;
+    int shared_with = -1;  // the dict dehazing set whose gray plane / atmospheric light are still in the workspace
+    for (int k = 0; k < n; ++k) {
+        const uwie_params *p = &ps[k];
+        Carver ck(sb.pipe);
+        Pipe P = carve_pipe(ck, s, p);
+        uint8_t *out = all + (size_t)k * frame_set;
+        if (p->surface == UWIE_SURFACE_SIX) {
+            UWIE_TRY(run_six(ctx, d_in, s, p, P, out, sb.f32, st));
+            shared_with = -1;
+        } else if (!dehazes(p)) {
+            UWIE_TRY(launch_code_strategy(ctx, d_in, nullptr, s, p, out, sb.f32, P.scratch, st));
+            shared_with = -1;
+        } else {
+            // one quadtree for all the dehazing sets that follow each other with the same leaf size and gray coefficients
+            const bool have = shared_with >= 0 && ps[shared_with].min_size == p->min_size && ps[shared_with].gray_shift == p->gray_shift &&
+                              ps[shared_with].gf_exact == p->gf_exact;
+            UWIE_TRY(run_dict_dehaze(ctx, d_in, s, p, P, out, sb.f32, st, nullptr, have));
+            if (!have) shared_with = k;
+        }
+        // (img * 255).astype(uint8) is what every score but colourfulness starts from; that one takes the float image
+        UWIE_TRY(launch_quality_scores(ctx, out, sb.f32, s, p->gray_shift, weights8 ? weights8 : kDefault,
+                                       d_scores + (size_t)k * batch * 9, sb.qa, st));
+    }
+    return launch_pick_best(d_scores, n, s, all, d_best, d_best_u8, st);
 }
 
 int uwie_diff_enhance_f32(uwie_ctx *ctx, const float *d_img, float *d_out, int batch, int H, int W, int planar,

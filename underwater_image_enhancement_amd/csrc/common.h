@@ -201,6 +201,9 @@ size_t quality_ws_bytes(Shape s);
 int launch_quality_scores(uwie_ctx *ctx, const uint8_t *d_u8, const float *d_f32, Shape s, int gray_shift,
                           const double *weights8, double *d_scores, void *ws, hipStream_t st);
 
+// best[b] = first argmax over the n strategies of scores[k][b][8]; d_out (optional) [B][H][W][3] = d_all[best[b]][b]
+int launch_pick_best(const double *d_scores, int n, Shape s, const uint8_t *d_all, int32_t *d_best, uint8_t *d_out, hipStream_t st);
+
 // k_guided.hip
 size_t guided_ws_bytes(Shape s);
 size_t box_ws_bytes(Shape s);

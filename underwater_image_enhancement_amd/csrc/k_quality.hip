@@ -188,7 +188,46 @@ QaBufs carve_qa(Carver &c, Shape s)
     return q;
 }
 
+// main.py:145: best_strategy = max(strategy_scores, key=strategy_scores.get) -- the first maximum in the strategies' order.
+// scores: [n][B][9] (the weighted total is entry 8)
+__global__ void k_pick_best(const double *__restrict__ scores, int n, int B, int32_t *__restrict__ best)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int k = 0;
+    double top = scores[(size_t)b * 9 + 8];
+    for (int i = 1; i < n; ++i) {
+        const double v = scores[((size_t)i * B + b) * 9 + 8];
+        if (v > top) { top = v; k = i; }
+    }
+    best[b] = k;
+}
+
+// out[b] = all[best[b]][b]: 16 bytes per thread (frames are 3 * npx bytes; the tail goes byte by byte)
+__global__ void __launch_bounds__(256) k_gather_best(const uint8_t *__restrict__ all, const int32_t *__restrict__ best, size_t frame_bytes,
+                                                     int B, uint8_t *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const uint8_t *src = all + ((size_t)best[b] * B + b) * frame_bytes;
+    uint8_t *dst = out + (size_t)b * frame_bytes;
+    const size_t n16 = (((size_t)(src - (const uint8_t *)nullptr) | (size_t)(dst - (uint8_t *)nullptr)) & 15) ? 0 : frame_bytes / 16;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (size_t i = n16 * 16 + blockIdx.x * 256 + threadIdx.x; i < frame_bytes; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+int launch_pick_best(const double *d_scores, int n, Shape s, const uint8_t *d_all, int32_t *d_best, uint8_t *d_out, hipStream_t st)
+{
+    UWIE_LAUNCH(k_pick_best, dim3(cdiv(s.B, 64)), dim3(64), 0, st, d_scores, n, s.B, d_best);
+    UWIE_LAUNCH_CHECK();
+    if (d_out) {
+        UWIE_LAUNCH(k_gather_best, dim3(grid_for(s.npx() * 3 / 16 + 1, 1024), s.B), dim3(256), 0, st, d_all, d_best, s.npx() * 3, s.B, d_out);
+        UWIE_LAUNCH_CHECK();
+    }
+    return UWIE_OK;
+}
 
 size_t quality_ws_bytes(Shape s)
 {

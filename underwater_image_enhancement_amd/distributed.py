@@ -89,6 +89,11 @@ def gather_frames(local, n_frames: int, dst: int = 0):
     others ``None``.  The root's receives are one group."""
     rank, world = dist.get_rank(), dist.get_world_size()
     local = local.to(comm_device())
+    # Ranks with an empty shard skip the point-to-point group below.  Under NCCL / RCCL a batched P2P that is the FIRST
+    # communication on a process group must involve every rank (it creates the communicator); scatter_frames and
+    # enhance_sharded broadcast first, a stand-alone gather does not -- so it opens with a collective of its own (4 bytes; it
+    # also tells every rank the root's frame shape is not needed from it: nothing else is exchanged here).
+    dist.broadcast(torch.zeros(1, dtype=torch.int32, device=local.device), src=dst)
     if rank != dst:
         if local.shape[0] > 0:
             _p2p([dist.P2POp(dist.isend, local.contiguous(), dst)])

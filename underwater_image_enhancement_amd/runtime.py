@@ -251,6 +251,26 @@ class Device:
                                            _ptr(out), _ptr(ws), ws.numel(), self.stream()))
         return out
 
+    def select_best_u8(self, frames, plist, weights=None, want_all: bool = False):
+        """main.py:118-146 on the device (uwie_select_best_u8): frames uint8 cuda [B,H,W,3], plist a list of UwieParams.
+        Returns (best index int32 [B], best image uint8 [B,H,W,3], scores float64 [n,B,9], all outputs [n,B,H,W,3] or None)."""
+        B, H, W = self._bhw(frames)
+        assert frames.dtype == torch.uint8
+        n = len(plist)
+        arr = (UwieParams * n)(*plist)
+        nbytes = self.lib.uwie_workspace_bytes_select(B, H, W, arr, n, int(want_all))
+        if nbytes == 0:
+            raise _lib.UwieError("select_best: batch/H/W or strategy count out of range")
+        ws = self.workspace(nbytes)
+        best = self.empty((B,), torch.int32)
+        img = self.empty((B, H, W, 3), torch.uint8)
+        scores = self.empty((n, B, 9), torch.float64)
+        every = self.empty((n, B, H, W, 3), torch.uint8) if want_all else None
+        w = (ctypes.c_double * 8)(*[float(x) for x in weights]) if weights is not None else None
+        check(self.lib.uwie_select_best_u8(self._ctx, _ptr(frames), B, H, W, arr, n, w, _ptr(img), _ptr(best), _ptr(scores),
+                                           _ptr(every), _ptr(ws), ws.numel(), self.stream()))
+        return best, img, scores, every
+
     # ------------------------------------------------------------------ stages
     def cast_classify(self, frames):
         B, H, W = self._bhw(frames)

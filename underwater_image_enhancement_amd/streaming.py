@@ -56,14 +56,24 @@ class StreamEnhancer:
         self.e_down[slot].synchronize()
         return self.h_in[slot]
 
-    def submit_slot(self, i: int, n: int | None = None):
+    def submit_slot(self, i: int, n: int | None = None, src=None):
+        """Start chunk ``i``: upload, enhance, download.  ``src`` (optional): a PINNED uint8 host tensor ``[n, H, W, 3]`` to upload
+        from instead of the slot's own input buffer -- frames that already sit in pinned memory (a capture ring, a decoder's
+        output) skip the staging copy altogether.  The caller keeps ``src`` untouched until the chunk's result is taken."""
         slot = i % self.depth
+        if src is not None:
+            if not src.is_pinned() or src.dtype != torch.uint8 or tuple(src.shape[1:]) != (self.H, self.W, 3) or src.shape[0] > self.chunk:
+                raise ValueError("src must be a pinned uint8 [<= chunk, H, W, 3] host tensor")
+            n = int(src.shape[0])
+            if any(s == slot for s, _ in self._pending):
+                raise RuntimeError("slot still holds an untaken result: call result() first")
+            self.e_down[slot].synchronize()
         n = self.chunk if n is None else int(n)
         d = self.dev
         with torch.cuda.stream(self.s_up):
             if self._used[slot]:
                 self.s_up.wait_event(self.e_run[slot])  # the slot's previous compute read d_in[slot]
-            self.d_in[slot][:n].copy_(self.h_in[slot][:n], non_blocking=True)
+            self.d_in[slot][:n].copy_((self.h_in[slot] if src is None else src)[:n], non_blocking=True)
             self.e_up[slot].record(self.s_up)
         with torch.cuda.stream(self.s_run):
             self.s_run.wait_event(self.e_up[slot])
