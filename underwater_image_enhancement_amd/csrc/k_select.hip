@@ -836,6 +836,45 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
     const V *L = lists + ((size_t)bc * kLinLists + g) * cap;
     uint32_t r = s->rr[q];
     const uint32_t tb = s->qbin[q];
+    // A whole window's list (tb == kLinAnyBin, the rank-counting sweep: several bins, ~1 % of the plane, 100 K elements at 4K)
+    // does not fit the LDS buffer, and every further pass over it in global memory is a dozen dependent round trips of a
+    // lone block (0.27 ms at 4K x 64).  So ONE pass bins its elements 2048 ways across the window's value range and finds the
+    // rank's sub-bin; from then on "mine" is that sub-bin's few dozen elements and everything else runs in LDS.
+    bool sub = false;
+    float sub_lo = 0.0f, sub_scale = 0.0f;
+    uint32_t sub_d = 0;
+    auto subbin = [&](V x) -> uint32_t {
+        const float f = ((float)x - sub_lo) * sub_scale;  // monotone in x: the same expression in every pass
+        return (uint32_t)fminf(fmaxf(f, 0.0f), 2047.0f);
+    };
+    if (tb == kLinAnyBin && cnt > (uint32_t)kBuf) {  // block-uniform
+        sub = true;
+        sub_lo = (float)(s->wlo[g] - 1u) * (1.0f / 2048.0f);
+        sub_scale = 2048.0f * 2048.0f / (float)(s->wspan[g] + 1u);
+        for (int i = tid; i < 2048; i += 1024) h[i] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < cnt; base += 8192) {
+            V x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = base + u * 1024 + tid;
+                x[u] = i < cnt ? L[i] : (V)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * 1024 + tid < cnt) atomicAdd(&h[subbin(x[u])], 1u);
+        }
+        __syncthreads();
+        uint32_t d, rr;
+        block_find_digit(h, 2048, r, wsum, found, d, rr);
+        sub_d = d;
+        r = rr;
+    }
+    const uint32_t r_mine = r;  // the query's rank among "mine"
+    auto is_mine = [&](V x, uint32_t i) -> bool {
+        if (tb != kLinAnyBin) return lin_digit(x) == tb;
+        return i < cnt && (!sub || subbin(x) == sub_d);
+    };
     if (tid == 0) {
         s_nloc = 0;
         s_kmin = ~0ull;
@@ -853,7 +892,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const bool mine = tb == kLinAnyBin ? base + u * 1024 + tid < cnt : lin_digit(x[u]) == tb;
+                const bool mine = is_mine(x[u], base + u * 1024 + tid);
                 const uint64_t m = __ballot(mine);
                 if (m) {  // wavefront-aggregated append
                     const int leader = (int)__builtin_ctzll(m);
@@ -905,7 +944,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
                     x[u] = i < cnt ? L[i] : (V)-1;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) take(x[u], tb == kLinAnyBin ? base + u * 1024 + tid < cnt : lin_digit(x[u]) == tb);
+                for (int u = 0; u < 8; ++u) take(x[u], is_mine(x[u], base + u * 1024 + tid));
             }
         }
         __syncthreads();
@@ -948,7 +987,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
             for (uint32_t base = 0; base < cnt; base += 1024) {
                 const uint32_t i = base + tid;
                 const V x = i < cnt ? L[i] : (V)-1;
-                look(x, tb == kLinAnyBin ? i < cnt : lin_digit(x) == tb);
+                look(x, is_mine(x, i));
             }
         }
         cle = wave_sum_u32(cle);
@@ -963,8 +1002,26 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         }
     }
     __syncthreads();
-    // rank_in_list(x_r) = rr[q]: the next one is x_r again if more than rr[q] + 1 elements are <= x_r
-    if (tid == 0) os[bc * kMaxRanks + q1] = Traits<V>::value((K)(s_nloc > s->rr[q1] ? prefix : s_kmin));
+    // x_r has rank r_mine among "mine": the next order statistic is x_r again if more than r_mine + 1 of them are <= x_r,
+    // else the smallest element above it -- of the sub-bin, or (none left there) of the rest of the list: one more pass
+    if (sub && s_nloc <= r_mine + 1u && s_kmin == ~0ull) {  // block-uniform
+        unsigned long long kgt = ~0ull;
+        for (uint32_t base = 0; base < cnt; base += 1024) {
+            const uint32_t i = base + tid;
+            if (i < cnt) {
+                const unsigned long long key = (unsigned long long)Traits<V>::key(L[i]);
+                if (key > prefix && key < kgt) kgt = key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = shfl_u64(kgt, lane ^ o);
+            kgt = a < kgt ? a : kgt;
+        }
+        if (lane == 0) atomicMin(&s_kmin, kgt);
+        __syncthreads();
+    }
+    if (tid == 0) os[bc * kMaxRanks + q1] = Traits<V>::value((K)(s_nloc > r_mine + 1u ? prefix : s_kmin));
 }
 
 struct LinBufs {
