@@ -537,3 +537,27 @@ def test_select_best_equals_the_labelling_loop_of_main_py(uw, orc):
     name1, img1, sc1 = uw.select_best(frames[0], strategies=sub, weights={"contrast": 1.0})
     assert name1 in ("CLAHEEnhancement", "LightEnhancement") and img1.shape == frames[0].shape and set(sc1) == {"CLAHEEnhancement", "LightEnhancement"}
     assert np.array_equal(img1, every[name1][0]) and name1 == max(sc1, key=sc1.get)
+
+
+def test_fused_transmission_route_gives_the_same_bytes(uw, orc):
+    """Tuning gf_fuse = 1 (k_guided_split8, round 4): the first half of estimate_transmission (S6:170-174 / ES:221-225) is
+    evaluated inside the guided filter from the frame's bytes -- the same float32 operations as k_trans_init, so the bytes are
+    those of the default route (and the oracle's) on both surfaces, for the float64 and the float32 transmission.  gf_bands
+    forces the split kernels onto frames this small; an edge strip on each side and interior strips are all there."""
+    from underwater_image_enhancement_amd import _lib
+    from test_gpu_configs import underwater
+
+    rng = np.random.default_rng(170)
+    dev = uw.get_device()
+    frames = [underwater(rng, 300, 520, (0.45, 0.85, 0.80)), rng.integers(0, 256, (260, 384, 3), dtype=np.uint8)]
+    for u8 in frames:
+        x = orc.normalise_u8(u8)
+        with dev.tuning(gf_bands=2):
+            base2 = uw.enhance(u8, strategy=2)
+            base2f = uw.enhance(u8, strategy=2, inter_dtype=_lib.INTER_F32T)
+            based = uw.EnhancementStrategies.apply_strategy(x, "strong_dehazing", orc.CONFIG_STRATEGIES["strong_dehazing"])
+            with dev.tuning(gf_fuse=1):
+                assert np.array_equal(uw.enhance(u8, strategy=2), base2)
+                assert np.array_equal(uw.enhance(u8, strategy=2, inter_dtype=_lib.INTER_F32T), base2f)
+                assert np.array_equal(uw.EnhancementStrategies.apply_strategy(x, "strong_dehazing", orc.CONFIG_STRATEGIES["strong_dehazing"]), based)
+        assert np.array_equal(base2, orc.enhance_u8(u8, 2))

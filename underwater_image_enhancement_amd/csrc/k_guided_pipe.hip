@@ -1035,6 +1035,18 @@ k_guided_split(const uint8_t *__restrict__ gray, const float *__restrict__ t0, T
     else split_body<K, false, TOut>(gray, t0, tout, g, cs, lds, bid);
 }
 
+// ---------------------------------------------------------------- measured and dropped (round 4): eight ADJACENT strips per workgroup
+// VERDICT r03 asked for the strips' 28-slot halo to be shared: eight wavefronts of one workgroup on adjacent 128-slot strips of a
+// 1024-slot group (996 columns out instead of 8 x 100), the staging lines of the eight end to end in LDS so that a lane's
+// look-ahead runs on into its right neighbour's entries, two LDS counters per wavefront (stagings done / read phases done,
+// polled with s_sleep, bounded) ordering "w reads what w + 1 staged" -- LDS filled to the byte (40 KB of lines + 8 x 15 KB of
+// rings = 160 KB, the counters in ring entries of lanes that own no slot).  Built, bit-exact against the tolerance tests on the
+// first run -- and SLOWER at 4K x 64 (A/B in one run): 3.32 ms against 2.82 for the lone strips.  With the waits and signals
+// compiled out (wrong results, timing only) it took 2.73 ms: the 20 % fewer slots buy 3 %, because a workgroup of eight
+// wavefronts that start, warm up and end together keeps a CU less busy than eight staggered lone wavefronts (k_guided_split8
+// below pays the same ~10 %), and two counter round trips per step (+0.6 ms) cost more than the halo.  The kernel is bound
+// by the latency chain of ONE wavefront's step at two wavefronts per SIMD; anything that adds to that chain loses.
+//
 // ---------------------------------------------------------------- the same strips, eight to a workgroup, t0 computed on the way in
 // Round 4: the raw transmission plane (k_trans_init: 3 B/px read, 4 written, then 4 read here; 0.72 ms at 4K x 64) is not
 // materialised.  t0 of a pixel is a function of its three bytes -- min_c(img_c / (A_c + eps)) through a 3 x 256 table of IEEE
