@@ -120,6 +120,9 @@ void uwie_destroy(uwie_ctx *ctx);
  *   UWIE_STATUS_CANNY_LABEL  cv2.Canny's hysteresis (S6:150; k_canny.hip union / mark / emit / paint) met a component
  *                            label that the current launch did not write. */
 #define UWIE_STATUS_CANNY_LABEL 1u
+/*   UWIE_STATUS_FALLBACK_SYNC  the blocks of a plane in the percentile selection's one-launch fallback (k_rank_fallback) gave up
+ *                              waiting for each other (seconds): the kernel terminated, that plane's percentiles are not valid. */
+#define UWIE_STATUS_FALLBACK_SYNC 2u
 int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits);
 
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference only has a per-image wall clock,
@@ -154,8 +157,11 @@ int uwie_params_init(uwie_params *p, int surface, int strategy);
 int uwie_set_tuning(uwie_ctx *ctx, const char *name, int value);
 int uwie_get_tuning(uwie_ctx *ctx, const char *name, int *value);
 
-/* Scratch bytes needed by uwie_enhance_u8 / any stage entry point for this shape. */
+/* Scratch bytes needed by uwie_enhance_u8 / any stage entry point for this shape, for a context with the DEFAULT route
+ * selectors (p = NULL: any call).  uwie_workspace_bytes_ctx answers for a given context: the tuning selectors restore_store and
+ * select_generic make the dehazing strategies keep the restored image in float32 planes (12 B/px more). */
 size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p);
+size_t uwie_workspace_bytes_ctx(uwie_ctx *ctx, int batch, int H, int W, const uwie_params *p);
 
 /*
  * enhance(u8 RGB) -> u8 RGB for a whole batch.

@@ -431,8 +431,10 @@ def test_select_paths_agree(uw, orc):
     big[::11, ::13] = rng.integers(0, 256, big[::11, ::13].shape, dtype=np.uint8)
     want_big = orc.enhance_u8(big, 2)
     dev = uw.get_device()
-    for store in (0, 1):
-        with dev.tuning(restore_store=store):
+    # (store, rank): stored planes or recomputation; for the latter the histogram sweep (the default below 16 MP) and round 4's
+    # rank-counting sweep (rank_sweep = 2 forces it onto these small frames), each through every fallback below
+    for store, rank in ((0, 1), (0, 2), (1, 1)):
+        with dev.tuning(restore_store=store, rank_sweep=rank):
             for name, u8 in (("noisy", noisy), ("flatish", flatish), ("odd", odd), ("wide", wide)):
                 for k in (1, 2, 3):
                     want = orc.enhance_u8(u8, k)
@@ -442,10 +444,7 @@ def test_select_paths_agree(uw, orc):
                     with dev.tuning(select_generic=1):
                         check_u8(uw.enhance(u8, strategy=k), want, f"generic sweeps only, strategy {k} on {name}, store={store}")
                     # the producer files the predicted windows (two, or strategy 3's four): off, still covering, missing
-                    # (rank_sweep = 0: the histogram sweep of rounds 1-3 instead of round 4's rank-counting sweep, which is the
-                    # default route of strategies 1-2 without stored planes and the one the shifted / missing windows exercise)
-                    for knob, val in (("lin_no_predict", 1), ("lin_predict_shift", 2), ("lin_predict_shift", 400), ("lin_predict3", 1),
-                                      ("rank_sweep", 0)):
+                    for knob, val in (("lin_no_predict", 1), ("lin_predict_shift", 2), ("lin_predict_shift", 400), ("lin_predict3", 1)):
                         with dev.tuning(**{knob: val}):
                             check_u8(uw.enhance(u8, strategy=k), want, f"{knob}={val}, strategy {k} on {name}, store={store}")
             check_u8(uw.enhance(big, strategy=2), want_big, f"stage overflow, strategy 2 on big flat frame, store={store}")

@@ -68,6 +68,7 @@ SIGNATURES = {
     "uwie_set_tuning": [_VP, ctypes.c_char_p, _I],
     "uwie_get_tuning": [_VP, ctypes.c_char_p, ctypes.POINTER(_I)],
     "uwie_workspace_bytes": [_I, _I, _I, _PP],
+    "uwie_workspace_bytes_ctx": [_VP, _I, _I, _I, _PP],
     "uwie_workspace_bytes_all": [_I, _I, _I, _VP],
     "uwie_workspace_bytes_float": [_I, _I, _I, _PP, _I],
     "uwie_enhance_f32": [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _PP, _VP, _SZ, _VP],
@@ -106,6 +107,7 @@ _RESTYPES = {
     "uwie_version": ctypes.c_char_p,
     "uwie_destroy": None,
     "uwie_workspace_bytes": ctypes.c_size_t,
+    "uwie_workspace_bytes_ctx": ctypes.c_size_t,
     "uwie_workspace_bytes_all": ctypes.c_size_t,
     "uwie_workspace_bytes_float": ctypes.c_size_t,
     "uwie_workspace_bytes_select": ctypes.c_size_t,

@@ -143,22 +143,32 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     if (dict_dz) {
         P.F64 = c.take<double>(n * 3);
         P.pct64 = c.take<double>((size_t)s.B * 3 * kMaxPct);
-    } else {
+    } else if (!p || (p->surface == UWIE_SURFACE_SIX && dz && (p->strategy == 3 || tune().restore_store || tune().select_generic))) {
+        // The float32 planes of the restored image (12 B/px): strategy 3's tail reads them, the stored-plane and key-sweep
+        // routes (tuning) work on them.  Strategies 1-2 recompute the image in every sweep and -- round 4 -- in the
+        // selection's fallback too, and the code-domain strategies never had a use for them: nothing reserved
+        // (a 4K x 64 strategy-2 call: 43 -> 31 B/px).  tune() is the calling context's tuning inside an entry point and the
+        // default tuning in uwie_workspace_bytes, which has no context: uwie_workspace_bytes_ctx answers for a context.
         P.F = c.take<float>(n * 3);
-    }
-    if (dz) {
-        P.gray = c.take<uint8_t>(n);
-        P.t0 = c.take<float>(n);
-        P.t = c.take<double>(n);
     }
     const int tx = p ? p->tiles_x : 8, ty = p ? p->tiles_y : 8;
     // the exact-order guided filter materialises six float64 planes; the default kernels keep everything on chip
     const bool gf_planes = dz && (!p || p->gf_exact || !guided_fast_handles(s, p->gf_ksize));
+    if (dz) {
+        P.gray = c.take<uint8_t>(n);
+        // The raw transmission lives from k_trans_init to the end of the guided filter.  The scratch region is idle exactly then
+        // (the quadtree is done with it, the selection has not started), so t0 borrows its first 4 B/px -- unless the exact-order
+        // filter is on, whose six planes are IN the scratch while it reads t0.
+        if (gf_planes) P.t0 = c.take<float>(n);
+        P.t = c.take<double>(n);
+    }
     P.scratch_bytes = max5(cast_ws_bytes(s), dz ? airlight_ws_bytes(s) : 0, gf_planes ? guided_ws_bytes(s) : 0,
                            select_ws_bytes(s), clahe_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8));
     const size_t cw = codes_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8);
     if (cw > P.scratch_bytes) P.scratch_bytes = cw;
+    if (dz && !gf_planes && P.scratch_bytes < n * sizeof(float)) P.scratch_bytes = n * sizeof(float);
     P.scratch = c.take<char>(P.scratch_bytes);
+    if (dz && !gf_planes) P.t0 = static_cast<float *>(P.scratch);
     return P;
 }
 
@@ -171,6 +181,7 @@ uwie_params merged_params(const uwie_params *ps, int n, Shape s)
     m.surface = UWIE_SURFACE_SIX;
     m.strategy = 2;
     for (int i = 0; i < n; ++i) {
+        if (ps[i].surface == UWIE_SURFACE_SIX && ps[i].strategy == 3) m.strategy = 3;  // (its tail reads the stored planes)
         if (ps[i].tiles_x > m.tiles_x) m.tiles_x = ps[i].tiles_x;
         if (ps[i].tiles_y > m.tiles_y) m.tiles_y = ps[i].tiles_y;
         if (ps[i].surface == UWIE_SURFACE_SIX && ps[i].strategy <= 3 &&
@@ -270,7 +281,10 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // Tuning lin_predict3 brings the windows back.
         const bool predict = k != 3 || tune().lin_predict3;
         UWIE_TRY(select_lin_begin(s, q, k == 3 ? 4 : 2, P.scratch, st, &plan, predict ? &src : nullptr));
-        if (recompute && plan.predicted && !t_is_f32 && tune().rank_sweep) {
+        // (small jobs keep the histogram sweep: at 1080p x 1 the rank-counting kernels' fixed costs -- wavefront-private queues,
+        // a window-wide list for the finish -- make them 54 + 20 us against 34 + 14; tuning rank_sweep = 2 forces them anyway)
+        const bool big = (size_t)s.B * s.npx() >= ((size_t)1 << 24) || tune().rank_sweep >= 2;
+        if (recompute && plan.predicted && !t_is_f32 && tune().rank_sweep && big) {
             // round 4: no histogram at all -- counts below the predicted windows + the windows' members (k_restore_rank)
             UWIE_TRY(launch_restore_rank(src, s, plan, st));
             UWIE_TRY(select_rank_run(plan, P.F, s, st, src));
@@ -586,7 +600,8 @@ int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits)
     if (bits) *bits = v;
     if (v) {
         set_error("device status 0x%x:%s the results of the calls since the last check are not valid", v,
-                  (v & UWIE_STATUS_CANNY_LABEL) ? " Canny hysteresis met a component label that this launch did not write (k_canny.hip);" : "");
+                  (v & UWIE_STATUS_CANNY_LABEL) ? " Canny hysteresis met a component label that this launch did not write (k_canny.hip);"
+                  : (v & UWIE_STATUS_FALLBACK_SYNC) ? " the percentile fallback's blocks gave up waiting for each other (k_select.hip);" : "");
         return UWIE_E_DEVICE;
     }
     return UWIE_OK;
@@ -729,6 +744,13 @@ size_t uwie_workspace_bytes(int batch, int H, int W, const uwie_params *p)
     const size_t al = airlight_ws_bytes(s) + (size_t)batch * s.npx() + 256;
     if (al > stage) stage = al;
     return pipe > stage ? pipe : stage;
+}
+
+size_t uwie_workspace_bytes_ctx(uwie_ctx *ctx, int batch, int H, int W, const uwie_params *p)
+{
+    if (!ctx) return uwie_workspace_bytes(batch, H, W, p);
+    CallScope scope(ctx);  // tune() answers for this context
+    return uwie_workspace_bytes(batch, H, W, p);
 }
 
 size_t uwie_workspace_bytes_all(int batch, int H, int W, const uwie_params *p6)

@@ -520,9 +520,10 @@ __global__ void __launch_bounds__(256) k_lin_predict(LinState *__restrict__ st, 
 template <typename V>
 __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, const uint32_t *__restrict__ ghist,
                                                   RankList ranks, V *__restrict__ os, uint32_t *__restrict__ flags,
-                                                  uint32_t cap)
+                                                  uint32_t cap, uint32_t *__restrict__ bar)
 {
     __shared__ uint32_t h[kLinBins], wsum[4], found[2], qbin[kMaxRanks], qrr[kMaxRanks];
+    if (bar && threadIdx.x == 0) bar[blockIdx.x] = 0;  // the one-launch fallback's per-plane barrier counter (k_rank_fallback)
     const int bc = blockIdx.x, tid = threadIdx.x;
     const uint32_t *gh = ghist + (size_t)bc * kSelGroupStride;
     for (int i = tid; i < kLinBins; i += 256) h[i] = gh[i];
@@ -576,10 +577,11 @@ __global__ void __launch_bounds__(256) k_lin_scan(LinState *__restrict__ st, con
 // exact ones only: a rank under a window that starts at bin 1 is 0, one above a window that ends at bin 2048 is 1.  Anything
 // else -- the prediction missed, or the list overflowed -- flags the plane for the generic sweeps.
 __global__ void k_rank_scan(LinState *__restrict__ st, RankList ranks, float *__restrict__ os, uint32_t *__restrict__ flags,
-                            uint32_t cap, int nbc)
+                            uint32_t cap, int nbc, uint32_t *__restrict__ bar)
 {
     const int bc = blockIdx.x * blockDim.x + threadIdx.x;
     if (bc >= nbc) return;
+    bar[bc] = 0;  // the fallback's per-plane barrier counter (k_rank_fallback)
     LinState s = st[bc];
     bool miss = false;
     for (int q = 0; q < kMaxRanks; ++q) { s.rr[q] = 0; s.qbin[q] = 0; s.gid[q] = kLinDone; s.gbin[q] = kLinDone; }
@@ -1024,6 +1026,111 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
     if (tid == 0) os[bc * kMaxRanks + q1] = Traits<V>::value((K)(s_nloc > r_mine + 1u ? prefix : s_kmin));
 }
 
+// The rank route's fallback in ONE launch (round 4): a plane the scan flagged -- a rank outside its predicted window, a list
+// that overflowed -- gets its four order statistics from three key-digit sweeps (11 + 11 + 10 bits, as k_sel_hist / k_sel_scan)
+// over values RECOMPUTED from the frame and the transmission: no stored float32 planes (12 B/px of workspace that a strategy-2
+// call no longer reserves), and one launch that returns at once for every unflagged plane instead of eleven that each do.
+// grid (G, B*3), block 256: the G blocks of a flagged plane meet at a counter in global memory between the sweeps.  Workgroups
+// are dispatched in the order of their linear index (x fastest), so the G blocks of a plane are dispatched together and the
+// blocks that wait can only be waiting for blocks that are resident or about to be: no deadlock while G fits the chip.  The
+// wait is bounded all the same (UWIE_STATUS_FALLBACK_SYNC).
+constexpr int kFallbackBlocks = 24;
+__global__ void __launch_bounds__(256) k_rank_fallback(RestoreSrc S, int npx, RankList ranks, const uint32_t *__restrict__ flags,
+                                                       uint32_t *__restrict__ ghist, uint32_t *__restrict__ bar, float *__restrict__ os,
+                                                       uint32_t *__restrict__ status)
+{
+    const int bc = blockIdx.y;
+    if (!flags[bc]) return;  // block-uniform: the common case
+    __shared__ uint32_t h[4][2048], wsum[4], found[2];
+    __shared__ uint32_t s_pre[4], s_rank[4];
+    const int b = bc / 3, c = bc % 3, tid = threadIdx.x, G = gridDim.x, nq = ranks.n;
+    uint32_t *gh = ghist + (size_t)bc * kMaxRanks * kBins;  // 16384 counters: sweep 0 [0, 2048), sweep 1 [2048, 10240), sweep 2 [10240, 14336)
+    uint32_t phase = 0;
+    auto plane_barrier = [&]() {
+        ++phase;
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            atomicAdd(&bar[bc], 1u);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&bar[bc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * (uint32_t)G) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) {  // seconds: a defect, not a wait
+                    atomicOr(status, (uint32_t)UWIE_STATUS_FALLBACK_SYNC);
+                    break;
+                }
+            }
+            __threadfence();
+        }
+        __syncthreads();
+    };
+    for (int i = blockIdx.x * 256 + tid; i < kMaxRanks * kBins; i += G * 256) gh[i] = 0;
+    plane_barrier();
+    RestoreImg R;
+    RestoreImg32 R32;  // UWIE_INTER_F32T: the float32 restore IS the value (restore.h pixel32)
+    if (S.t32) R32.init(S, b, (size_t)npx);
+    else R.init(S, b, (size_t)npx);
+    const int per = (npx + G - 1) / G, lo = min(npx, (int)blockIdx.x * per), hi = min(npx, lo + per);
+    uint32_t pre[4] = {0, 0, 0, 0}, rk[4] = {0, 0, 0, 0}, gpre[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) rk[q] = q < nq ? ranks.r[q] : ranks.r[0];
+    int ng = 1;
+    uint32_t goff = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = Traits<float>::shift(pass), bits = Traits<float>::bits(pass), nbins = 1 << bits;
+        for (int i = tid; i < ng * nbins; i += 256) (&h[0][0])[(i / nbins) * 2048 + (i % nbins)] = 0;
+        __syncthreads();
+        for (int p = lo + tid; p < hi; p += 256) {
+            float v;
+            if (S.t32) {
+                const uint32_t u = R32.img[(size_t)p * 3 + c];
+                v = fminf(fmaxf(R32.one32_raw(u, c, R32.recip32(R32.tf()[p])), 0.0f), 1.0f);
+            } else {
+                const uint32_t u = R.img[(size_t)p * 3 + c];
+                const double tv = R.t[p];
+                v = R.recip_ok(tv) ? R.one_fast(u, c, tv, R.recip(tv)) : R.one(u, c, tv);
+            }
+            const uint32_t key = f32_key(v), d = (key >> shift) & (uint32_t)(nbins - 1), hp = pass ? key >> (shift + bits) : 0u;
+            for (int g = 0; g < ng; ++g)
+                if (hp == gpre[g]) atomicAdd(&h[g][d], 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < ng * nbins; i += 256) {
+            const uint32_t cnt = h[i / nbins][i % nbins];
+            if (cnt) atomicAdd(&gh[goff + (uint32_t)i], cnt);
+        }
+        plane_barrier();
+        for (int i = tid; i < ng * nbins; i += 256) h[i / nbins][i % nbins] = __hip_atomic_load(&gh[goff + (uint32_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        // every block narrows the four queries by this digit (redundantly: no second barrier), then regroups the prefixes
+        for (int q = 0; q < 4; ++q) {
+            int g = 0;
+            for (int j = 0; j < ng; ++j)
+                if (pre[q] == gpre[j]) g = j;
+            uint32_t d, rr;
+            block_find_digit(h[g], nbins, rk[q], wsum, found, d, rr);
+            if (tid == 0) {
+                s_pre[q] = (pre[q] << bits) | d;
+                s_rank[q] = rr;
+            }
+            __syncthreads();
+        }
+        for (int q = 0; q < 4; ++q) {
+            pre[q] = s_pre[q];
+            rk[q] = s_rank[q];
+        }
+        __syncthreads();
+        goff += (uint32_t)(ng * nbins);
+        ng = 0;
+        for (int q = 0; q < 4; ++q) {
+            bool seen = false;
+            for (int j = 0; j < ng; ++j) seen = seen || gpre[j] == pre[q];
+            if (!seen) gpre[ng++] = pre[q];
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0)
+        for (int q = 0; q < nq; ++q) os[bc * kMaxRanks + q] = Traits<float>::value(pre[q]);
+}
+
 struct LinBufs {
     LinState *lin;
     float *lists;
@@ -1102,7 +1209,8 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
     UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
-    UWIE_LAUNCH(k_lin_scan<float>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap);
+    UWIE_LAUNCH(k_lin_scan<float>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (float *)plan.os, plan.flags, plan.cap,
+                src ? reinterpret_cast<uint32_t *>(plan.state) : (uint32_t *)nullptr);
     UWIE_LAUNCH_CHECK();
     int blocks = (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);
@@ -1121,11 +1229,16 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
                 plan.flags, 0);
     UWIE_LAUNCH_CHECK();
-    // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
-    // flagged images are written out first
+    // the flagged planes (their kernels return at once for the others).  Recomputed values: the one-launch fallback, no stored
+    // planes (round 4; rounds 1-3 wrote the flagged images out and ran the generic chain: eleven launches and 12 B/px of
+    // workspace).  Stored planes: the generic three-digit sweeps on them.
     if (src) {
-        const int rc = launch_restore_planar_hist(src->in, src->kind, src->A, src->t, s, d_planar, nullptr, st, true, plan.flags, nullptr, src->t32);
-        if (rc != UWIE_OK) return rc;
+        uwie_ctx *ctx = current_ctx();
+        UWIE_REQUIRE(ctx != nullptr, "select_lin_run: needs a context");
+        UWIE_LAUNCH(k_rank_fallback, dim3(kFallbackBlocks, nbc), dim3(256), 0, st, *src, n, ranks, plan.flags, plan.ghist,
+                    reinterpret_cast<uint32_t *>(plan.state), (float *)plan.os, ctx->d_status);
+        UWIE_LAUNCH_CHECK();
+        return UWIE_OK;
     }
     UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
     UWIE_LAUNCH_CHECK();
@@ -1133,7 +1246,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     return run_t<float>(plan, d_planar, 1, s, false, st, plan.flags);
 }
 
-// After launch_restore_rank: scan -> finish on the window lists; flagged planes take the generic sweeps as in select_lin_run.
+// After launch_restore_rank: scan -> finish on the window lists; flagged planes take the fallback above.
 int select_rank_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t st, const RestoreSrc &src)
 {
     const int nbc = s.B * 3;
@@ -1141,17 +1254,20 @@ int select_rank_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_
     ranks.n = 2 * plan.nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
     LinState *lin = (LinState *)plan.lin;
-    UWIE_LAUNCH(k_rank_scan, dim3(cdiv(nbc, 64)), dim3(64), 0, st, lin, ranks, (float *)plan.os, plan.flags, plan.cap, nbc);
+    UWIE_LAUNCH(k_rank_scan, dim3(cdiv(nbc, 64)), dim3(64), 0, st, lin, ranks, (float *)plan.os, plan.flags, plan.cap, nbc,
+                reinterpret_cast<uint32_t *>(plan.state));
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
                 plan.flags, 1);
     UWIE_LAUNCH_CHECK();
-    const int rc = launch_restore_planar_hist(src.in, src.kind, src.A, src.t, s, d_planar, nullptr, st, true, plan.flags, nullptr, src.t32);
-    if (rc != UWIE_OK) return rc;
-    UWIE_LAUNCH(k_sel_init<uint32_t>, dim3(cdiv(nbc, 64)), dim3(64), 0, st, (SelState<uint32_t> *)plan.state, nbc, ranks);
+    (void)d_planar;  // (no stored planes on this route)
+    uwie_ctx *ctx = current_ctx();
+    UWIE_REQUIRE(ctx != nullptr && ranks.n <= 4, "select_rank_run: needs a context and at most two percentiles");
+    // the barrier counters: one word per plane in the selection state's memory, cleared by k_rank_scan
+    UWIE_LAUNCH(k_rank_fallback, dim3(kFallbackBlocks, nbc), dim3(256), 0, st, src, (int)s.npx(), ranks, plan.flags, plan.ghist,
+                reinterpret_cast<uint32_t *>(plan.state), (float *)plan.os, ctx->d_status);
     UWIE_LAUNCH_CHECK();
-    UWIE_HIP_CHECK(hipMemsetAsync(plan.ghist, 0, sizeof(uint32_t) * (size_t)nbc * kMaxRanks * kBins, st));
-    return run_t<float>(plan, d_planar, 1, s, false, st, plan.flags);
+    return UWIE_OK;
 }
 
 // float64 planes (ES surface): the same selection without the prediction; the lists hold doubles
@@ -1208,7 +1324,8 @@ int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStrea
     UWIE_REQUIRE(!src || ranks.n <= 4, "select_lin_run64: the recomputing sweep handles at most two percentiles");
     LinState *lin = (LinState *)plan.lin;
     double *lists = reinterpret_cast<double *>(plan.lists);
-    UWIE_LAUNCH(k_lin_scan<double>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (double *)plan.os, plan.flags, plan.cap);
+    UWIE_LAUNCH(k_lin_scan<double>, dim3(nbc), dim3(256), 0, st, lin, plan.ghist, ranks, (double *)plan.os, plan.flags, plan.cap,
+                (uint32_t *)nullptr);
     UWIE_LAUNCH_CHECK();
     int blocks = (int)(((long long)n + 131071) / 131072);
     if (blocks * nbc < 1024) blocks = cdiv(1024, nbc);

@@ -67,7 +67,7 @@ class Device:
         return p
 
     def workspace_for(self, B, H, W, p: UwieParams | None = None):
-        n = self.lib.uwie_workspace_bytes(B, H, W, ctypes.byref(p) if p is not None else None)
+        n = self.lib.uwie_workspace_bytes_ctx(self._ctx, B, H, W, ctypes.byref(p) if p is not None else None)
         if n == 0:
             raise _lib.UwieError("batch/H/W out of range")
         return self.workspace(n)

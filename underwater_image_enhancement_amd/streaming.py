@@ -37,7 +37,7 @@ class StreamEnhancer:
         self.h_out = [torch.empty(shape, dtype=torch.uint8, pin_memory=True) for _ in range(depth)]
         self.d_in = [torch.empty(shape, dtype=torch.uint8, device=d.torch_device) for _ in range(depth)]
         self.d_out = [torch.empty(shape, dtype=torch.uint8, device=d.torch_device) for _ in range(depth)]
-        nbytes = d.lib.uwie_workspace_bytes(self.chunk, self.H, self.W, ctypes.byref(self.p))
+        nbytes = d.lib.uwie_workspace_bytes_ctx(d._ctx, self.chunk, self.H, self.W, ctypes.byref(self.p))
         self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=d.torch_device)  # one: compute is serial anyway
         self.s_up, self.s_run, self.s_down = (torch.cuda.Stream(d.torch_device) for _ in range(3))
         self.e_up = [torch.cuda.Event() for _ in range(depth)]
