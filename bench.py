@@ -133,7 +133,7 @@ def cpu_baseline(frames_host, gpu_out_host, strategy, dist):
             "gpu_vs_oracle_bytes_compared": nbytes}
 
 
-TRAFFIC_PROFILE = "profiles/r03_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_traffic.json"
 
 
 def measured_traffic(kernel, H, W, B, strategy, launches_per_step, dist="underwater"):
@@ -215,10 +215,33 @@ def extras(dev, args, torch, _lib):
     dev.enhance_all_u8(fan)
     torch.cuda.synchronize()
     res["all_six_strategies_input_megapixels_per_sec"] = round(fan.shape[0] * H * W / 1e6 / (time.perf_counter() - t0), 1)
+    # N2's purpose (main.py:118-146): the five Config.STRATEGIES on every frame, comprehensive_assessment of each result, the
+    # best one -- one device call (uwie_select_best_u8; input pixels per second, every frame enhanced five times and scored)
+    import underwater_image_enhancement_amd as uw
+    from underwater_image_enhancement_amd.api import CONFIG_QUALITY_WEIGHTS, CONFIG_STRATEGIES, QUALITY_KEYS, _dict_params
+
+    plist = [_dict_params(dev, k, v) for k, v in CONFIG_STRATEGIES.items()]
+    wts = [CONFIG_QUALITY_WEIGHTS.get(k, 0) for k in QUALITY_KEYS]
+    dev.select_best_u8(fan, plist, wts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.select_best_u8(fan, plist, wts)
+    torch.cuda.synchronize()
+    res["select_best_of_five_input_megapixels_per_sec"] = round(fan.shape[0] * H * W / 1e6 / (time.perf_counter() - t0), 1)
+    # the rank-counting sweep's two kernels against the histogram sweep's (both selections of one recorded step each)
+    if args.strategy in (1, 2):
+        fr = synth_frames(args.dist, B, H, W, dev.torch_device, seed=1000 * 2)
+        for tag, knob in (("rank", 1), ("hist", 0)):
+            with dev.tuning(rank_sweep=knob):
+                dev.profile(True)
+                timed_enhance(dev, _lib, torch, fr, args.strategy, 1)
+                rows = dev.profile_rows()
+                dev.profile(False)
+            res[f"selection_{tag}_sweep_ms"] = round(sum(v[0] / max(v[1], 1) for n, v in rows.items()
+                                                       if n.startswith(("k_restore_rank", "k_restore_hist_collect", "k_lin_", "k_rank_"))), 3)
+        del fr
     del fan
     # configs[4] on one GPU: 4K frames from pinned host memory and back, copies overlapped with compute (PCIe-inclusive)
-    import underwater_image_enhancement_amd as uw
-
     chunk, nchunks = 8, 8
     se = uw.StreamEnhancer(H, W, chunk=chunk, depth=3, strategy=args.strategy)
     src = synth_frames("underwater", chunk, H, W, dev.torch_device, seed=1000 * 4).cpu()
