@@ -291,6 +291,10 @@ struct LinState {
                                             // wlo .. wlo + wspan (wlo = kLinNoWin: none), list = window
     uint32_t below[kMaxPct];     // (rank-counting sweep, k_restore_rank) elements in the bins below window w
 };
+// The rank route has two windows per plane, not kLinLists lists: the same memory as 2 lists of kRankCapMul x cap elements (a window
+// of whole histogram bins holds 1 - 2 % of a plane whose values cluster on a few levels -- hazy noise frames: 139 K of 8.3 M -- and
+// the histogram route's cap of 1/64 overflowed there on two planes in 192)
+constexpr int kRankCapMul = 4;
 constexpr uint32_t kLinAnyBin = 0xfffffffeu;  // LinState::qbin: the query's list is its whole window, rr its rank inside it
 struct RestoreSrc;
 // predict != nullptr: the target bins are predicted from a subsample of the restored image (k_lin_sample)

@@ -370,7 +370,7 @@ __device__ __forceinline__ void rank_flush_stage(const RankWave &X, int j, uint3
     uint32_t base = 0;
     if (X.lane == 0) base = atomicAdd(X.gcount0 + (size_t)c * X.gstride + w, n);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    float *L = X.lists0 + ((size_t)c * kLinLists + w) * X.cap;
+    float *L = X.lists0 + ((size_t)c * (kLinLists / kRankCapMul) + w) * X.cap;
     wave_lds_sync();
     for (uint32_t i = X.lane; i < n; i += 64)
         if (base + i < X.cap) L[base + i] = X.mystg[j][i];
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) k_restore_rank(RestoreSrc S, int npx, Lin
 
     const RankWave X{img, tpl, ftab, a0, a1, a2, s_wlo, s_wspan, s_lo, s_hi, s_below, myq, wstg[wv],
                      &lin[3 * b].gcount[0], (uint32_t)(sizeof(LinState) / sizeof(uint32_t)),
-                     lists + (size_t)(3 * b) * kLinLists * cap, cap, lane};
+                     lists + (size_t)(3 * b) * (kLinLists / kRankCapMul) * cap, cap, lane};
 
     const int step = gridDim.x * 1024, iters = (npx + step - 1) / step;  // block-uniform trip count
     typedef uint32_t __attribute__((aligned(1))) u32_a1;
@@ -1419,7 +1419,8 @@ int launch_restore_rank(const RestoreSrc &src, Shape s, const SelectPlan &plan, 
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
-    UWIE_LAUNCH(k_restore_rank, dim3(nblk, s.B), dim3(256), 0, st, src, (int)s.npx(), (LinState *)plan.lin, plan.lists, plan.cap);
+    UWIE_LAUNCH(k_restore_rank, dim3(nblk, s.B), dim3(256), 0, st, src, (int)s.npx(), (LinState *)plan.lin, plan.lists,
+                (uint32_t)kRankCapMul * plan.cap);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -805,7 +805,8 @@ __global__ void __launch_bounds__(256) k_lin_collect_src(RestoreSrc S, int n, Li
 // elements spread evenly.
 template <typename V>
 __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict__ st, const V *__restrict__ lists,
-                                                     uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags, int pair)
+                                                     uint32_t cap, V *__restrict__ os, uint32_t *__restrict__ flags, int pair,
+                                                     int nlists)
 {
     using K = typename Traits<V>::K;
     constexpr int kBuf = 49152 / (int)sizeof(V);
@@ -835,7 +836,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         if (tid == 0) flags[bc] = 1;
         return;
     }
-    const V *L = lists + ((size_t)bc * kLinLists + g) * cap;
+    const V *L = lists + ((size_t)bc * nlists + g) * cap;  // (nlists lists of `cap` elements per plane: kLinLists, or 2 four times as long)
     uint32_t r = s->rr[q];
     const uint32_t tb = s->qbin[q];
     // A whole window's list (tb == kLinAnyBin, the rank-counting sweep: several bins, ~1 % of the plane, 100 K elements at 4K)
@@ -1034,7 +1035,7 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
 // are dispatched in the order of their linear index (x fastest), so the G blocks of a plane are dispatched together and the
 // blocks that wait can only be waiting for blocks that are resident or about to be: no deadlock while G fits the chip.  The
 // wait is bounded all the same (UWIE_STATUS_FALLBACK_SYNC).
-constexpr int kFallbackBlocks = 24;
+constexpr int kFallbackBlocks = 96;  // (24 took 2.8 ms for two flagged 4K planes: a block then sweeps 346 K pixels three times)
 __global__ void __launch_bounds__(256) k_rank_fallback(RestoreSrc S, int npx, RankList ranks, const uint32_t *__restrict__ flags,
                                                        uint32_t *__restrict__ ghist, uint32_t *__restrict__ bar, float *__restrict__ os,
                                                        uint32_t *__restrict__ status)
@@ -1227,7 +1228,7 @@ int select_lin_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_t
     }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
-                plan.flags, 0);
+                plan.flags, 0, kLinLists);
     UWIE_LAUNCH_CHECK();
     // the flagged planes (their kernels return at once for the others).  Recomputed values: the one-launch fallback, no stored
     // planes (round 4; rounds 1-3 wrote the flagged images out and ran the generic chain: eleven launches and 12 B/px of
@@ -1254,11 +1255,11 @@ int select_rank_run(const SelectPlan &plan, float *d_planar, Shape s, hipStream_
     ranks.n = 2 * plan.nq;
     for (int j = 0; j < ranks.n; ++j) ranks.r[j] = plan.ranks[j];
     LinState *lin = (LinState *)plan.lin;
-    UWIE_LAUNCH(k_rank_scan, dim3(cdiv(nbc, 64)), dim3(64), 0, st, lin, ranks, (float *)plan.os, plan.flags, plan.cap, nbc,
+    UWIE_LAUNCH(k_rank_scan, dim3(cdiv(nbc, 64)), dim3(64), 0, st, lin, ranks, (float *)plan.os, plan.flags, kRankCapMul * plan.cap, nbc,
                 reinterpret_cast<uint32_t *>(plan.state));
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, plan.cap, (float *)plan.os,
-                plan.flags, 1);
+    UWIE_LAUNCH(k_lin_finish<float>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const float *)plan.lists, kRankCapMul * plan.cap,
+                (float *)plan.os, plan.flags, 1, kLinLists / kRankCapMul);
     UWIE_LAUNCH_CHECK();
     (void)d_planar;  // (no stored planes on this route)
     uwie_ctx *ctx = current_ctx();
@@ -1340,7 +1341,7 @@ int select_lin_run64(const SelectPlan &plan, double *d_planar, Shape s, hipStrea
     }
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_lin_finish<double>, dim3(nbc, ranks.n), dim3(1024), 0, st, lin, (const double *)lists, plan.cap, (double *)plan.os,
-                plan.flags, 0);
+                plan.flags, 0, kLinLists);
     UWIE_LAUNCH_CHECK();
     // generic path for the flagged planes (its kernels return at once for the others); without stored planes the
     // flagged images are written out first
