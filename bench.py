@@ -367,19 +367,24 @@ def main_stream(args, uw, _lib, torch, world, rank, local, rehearsal):
         host[b0:b0 + n].copy_(synth_frames(args.dist, n, H, W, dev.torch_device, seed=5000 + 100 * rank + b0))
     torch.cuda.synchronize()
     se = uw.StreamEnhancer(H, W, chunk, depth=3, strategy=args.strategy, device=local, **over)
-    sink = torch.empty((B, H, W, 3), dtype=torch.uint8, pin_memory=True)
+    first = torch.empty((1, H, W, 3), dtype=torch.uint8)
 
     def step():
+        # results are consumed where they land, in the ring's pinned output buffers (valid until depth - 1 further chunks have
+        # been taken): the timed region holds no host-to-host copy -- a single-threaded 200 MB memcpy per chunk was 85 % of the
+        # first version's step
         done = 0
         for i, b0 in enumerate(range(0, B, chunk)):
             if len(se._pending) == se.depth - 1:
                 r = se.result()
-                sink[done:done + r.shape[0]].copy_(r)  # the consumer's copy out of the ring (host to host)
+                if done == 0:
+                    first.copy_(r[:1])
                 done += r.shape[0]
             se.submit_slot(i, src=host[b0:b0 + min(chunk, B - b0)])
         while se._pending:
             r = se.result()
-            sink[done:done + r.shape[0]].copy_(r)
+            if done == 0:
+                first.copy_(r[:1])
             done += r.shape[0]
         assert done == B
 
@@ -405,7 +410,7 @@ def main_stream(args, uw, _lib, torch, world, rank, local, rehearsal):
         check = None
         if not args.no_cpu_baseline:  # the first frame against a direct device call on the same bytes (the ring changes nothing)
             direct = uw.enhance(host[:1].numpy(), strategy=args.strategy, device=local, **over)
-            check = int((direct.astype(int) - sink[:1].numpy().astype(int)).__abs__().max())
+            check = int((direct.astype(int) - first.numpy().astype(int)).__abs__().max())
         print(json.dumps({
             "metric": "megapixels/sec enhanced", "value": round(world * B * H * W * args.steps / elapsed / 1e6, 2),
             "unit": "megapixels/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -413,7 +418,7 @@ def main_stream(args, uw, _lib, torch, world, rank, local, rehearsal):
             "vs_baseline": None, "dtype": "f32/f32" if args.inter == "f32t" else "f32/f64", "data": "synthetic",
             "config": {"workload": f"{W}x{H} RGB u8 ({args.dist}) stream: {B} frames per GPU from pinned host memory in chunks of "
                                    f"{chunk}, upload / strategy{args.strategy} + cast correction / download overlapped on three streams, "
-                                   f"results back in pinned host memory (PCIe-inclusive; BASELINE.json configs[4]; intermediates "
+                                   f"results left in the ring's pinned host buffers (PCIe-inclusive; BASELINE.json configs[4]; intermediates "
                                    f"{args.inter}{'; gloo rehearsal, every rank on GPU 0' if rehearsal else ''})",
                        "frames_per_gpu": B, "chunk": chunk, "height": H, "width": W, "parallelism": f"independent streams x{world}"},
             "stream_vs_direct_max_lsb": check}))
