@@ -123,6 +123,10 @@ void uwie_destroy(uwie_ctx *ctx);
 /*   UWIE_STATUS_FALLBACK_SYNC  the blocks of a plane in the percentile selection's one-launch fallback (k_rank_fallback) gave up
  *                              waiting for each other (seconds): the kernel terminated, that plane's percentiles are not valid. */
 #define UWIE_STATUS_FALLBACK_SYNC 2u
+/*   UWIE_STATUS_QTREE_BOUNDS   (tuning q_hist = 3 only: a checking route) a quadrant's reference-order score (compute_Q, S6:116-157)
+ *                              fell outside the interval derived from its byte histogram, or the histogram route's decision
+ *                              differs from the reference-order argmax: the rounding bounds of k_q_decide / k_q_tail are too tight. */
+#define UWIE_STATUS_QTREE_BOUNDS 4u
 int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits);
 
 /* Per-kernel timing for benchmarks (no reference counterpart; the reference only has a per-image wall clock,
@@ -145,7 +149,8 @@ int uwie_params_init(uwie_params *p, int surface, int strategy);
  *   SAME BYTES on every setting -- the selection, storage and quadtree routes: select_generic (0), restore_store (0),
  *     lin_predict3 (0), lin_cap (0 = default), lin_no_predict (0), lin_predict_shift (0), rank_sweep (1: strategies 1-2 count
  *     ranks against the predicted windows; 0: the histogram sweep), q_hist (1: quadtree levels decided from byte histograms where
- *     the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used), canny_prepass (1),
+ *     the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used; 3: both, and every reference-order
+ *     score is checked against its interval -- UWIE_STATUS_QTREE_BOUNDS), canny_prepass (1),
  *     streams (1; 2 .. 4 = sub-batches on internal streams), gf_fuse (1: the transmission's first half is evaluated inside the
  *     guided filter for window 15, same float32 operations; 0: k_trans_init writes a t0 plane first);
  *   SAME TRANSMISSION TO 1e-11, hence the u8 contract of uwie_params.gf_exact = 0 -- which fused guided-filter kernel runs:

@@ -63,3 +63,39 @@ def test_tile_lut_kernel_with_idle_lanes_in_its_prefetch_branch(uw):
         for k in (1, 2):
             d = np.abs(uw.enhance(u8, strategy=k).astype(int) - orc.enhance_u8(u8, k).astype(int))
             assert d.max() <= (1 if k == 1 else 0), f"{H}x{W} strategy {k}: {d.max()} LSB, {np.count_nonzero(d)} bytes differ"
+
+
+def test_quadtree_scores_lie_inside_their_histogram_intervals(uw):
+    """the histogram-decided quadtree levels rest on hand-derived rounding bounds ((nch + 35) u, (nch + 38) u, 8 u of
+    slack, times 1.25); route-equality tests only show that no decision differed on the frames tried.  Tuning q_hist = 3 takes
+    the histograms AND runs the reference-order kernels, and the device itself checks, for every launched level and every level
+    of k_q_tail, that each quadrant's reference-order score lies inside its interval and that a decision the intervals allowed
+    is the reference argmax (UWIE_STATUS_QTREE_BOUNDS otherwise).  Adversarial inputs: near-tie quadrants, a saturated frame,
+    black, flat, two-level, noise with many 8192-element chunks per quadrant (a 4K frame), every cast kind."""
+    import torch
+
+    dev = uw.get_device()
+    rng = np.random.default_rng(314)
+    H, W = 460, 700
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8), np.full((H, W, 3), 255, np.uint8), np.zeros((H, W, 3), np.uint8),
+              np.full((H, W, 3), 97, np.uint8), np.clip(rng.normal(128, 3, (H, W, 3)), 0, 255).astype(np.uint8),
+              np.clip(rng.normal(250, 6, (H, W, 3)), 0, 255).astype(np.uint8)]
+    tie = np.full((H, W, 3), 120, np.uint8)  # four quadrants that differ in one pixel each
+    for i, (y, x) in enumerate(((10, 10), (10, 600), (400, 10), (400, 600))):
+        tie[y, x] = 121 + i
+    frames.append(tie)
+    batch = dev.tensor(np.stack(frames))
+    for kind_id in (0, 1, 2):
+        kk = torch.full((len(frames),), kind_id, dtype=torch.int32, device=dev.torch_device)
+        with dev.tuning(q_hist=1):
+            want = dev.atmospheric_light(batch, kk).cpu().numpy()
+        with dev.tuning(q_hist=3):
+            got = dev.atmospheric_light(batch, kk).cpu().numpy()
+            dev.check_status()  # raises on UWIE_STATUS_QTREE_BOUNDS
+        assert np.array_equal(got, want), kind_id
+    big = rng.integers(0, 256, (2, 2160, 3840, 3), dtype=np.uint8)  # 253 chunks per level-0 quadrant
+    big[1] = np.clip(big[1].astype(int) // 8 + 200, 0, 255).astype(np.uint8)
+    with dev.tuning(q_hist=3):
+        a3 = dev.atmospheric_light(dev.tensor(big)).cpu().numpy()
+        dev.check_status()
+    assert np.array_equal(a3, dev.atmospheric_light(dev.tensor(big)).cpu().numpy())

@@ -601,7 +601,8 @@ int uwie_device_status(uwie_ctx *ctx, void *stream, uint32_t *bits)
     if (v) {
         set_error("device status 0x%x:%s the results of the calls since the last check are not valid", v,
                   (v & UWIE_STATUS_CANNY_LABEL) ? " Canny hysteresis met a component label that this launch did not write (k_canny.hip);"
-                  : (v & UWIE_STATUS_FALLBACK_SYNC) ? " the percentile fallback's blocks gave up waiting for each other (k_select.hip);" : "");
+                  : (v & UWIE_STATUS_FALLBACK_SYNC) ? " the percentile fallback's blocks gave up waiting for each other (k_select.hip);"
+                  : (v & UWIE_STATUS_QTREE_BOUNDS) ? " a quadtree score fell outside its histogram interval (k_airlight.hip, tuning q_hist = 3);" : "");
         return UWIE_E_DEVICE;
     }
     return UWIE_OK;

@@ -37,6 +37,7 @@ struct LevelBufs {
     uint32_t *edges;   // [4B] Canny edge counts
     uint32_t *hist;    // [4B][3][256] byte histograms of the quadrants (k_q_hist)
     uint8_t *skip;     // [B] 1: the level was decided from the histograms, the exact kernels return at once
+    double *chk;       // [B][9] tuning q_hist = 3: the level's four score intervals and the decision taken from them, for k_q_select to verify
 };
 
 __global__ void k_init_blocks(Region *blk, int B, int H, int W)
@@ -554,7 +555,8 @@ __global__ void __launch_bounds__(256) k_q_hist(const uint8_t *__restrict__ in, 
 __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Region *__restrict__ regs,
                                                   const uint32_t *hist, uint32_t *__restrict__ edges,
                                                   const int32_t *__restrict__ kind, int min_size, int force_exact,
-                                                  uint8_t *__restrict__ skip, uint32_t *__restrict__ strong)
+                                                  uint8_t *__restrict__ skip, uint32_t *__restrict__ strong,
+                                                  double *__restrict__ chk = nullptr)
 {
     __shared__ double s_lo[4], s_hi[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -640,6 +642,15 @@ __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Regi
     bool sure = true;
     for (int i = 0; i < 4; ++i)
         if (i != arg && !(s_lo[arg] > s_hi[i])) sure = false;
+    if (chk) {  // tuning q_hist = 3: nothing is decided here -- the exact kernels run and k_q_select checks these against their scores
+        for (int i = 0; i < 4; ++i) {
+            chk[b * 9 + i] = s_lo[i];
+            chk[b * 9 + 4 + i] = s_hi[i];
+        }
+        chk[b * 9 + 8] = sure ? (double)arg : -1.0;
+        skip[b] = 0;
+        return;
+    }
     skip[b] = sure ? 1 : 0;
     if (sure) q_descend(blk, regs, edges, b, arg, min_size);
 }
@@ -653,7 +664,8 @@ __global__ void __launch_bounds__(256) k_q_decide(Region *__restrict__ blk, Regi
 __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Region *__restrict__ regs,
                                                  const float *__restrict__ csum, const float *__restrict__ csum_var, int maxChunks,
                                                  uint32_t *__restrict__ edges, int B, int level, int min_size,
-                                                 TraceRec *__restrict__ trace, const uint8_t *__restrict__ skip = nullptr)
+                                                 TraceRec *__restrict__ trace, const uint8_t *__restrict__ skip = nullptr,
+                                                 const double *__restrict__ chk = nullptr, uint32_t *__restrict__ status = nullptr)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (regs[b * 4].rows == 0) return;  // leaf reached earlier
@@ -711,6 +723,14 @@ __global__ void __launch_bounds__(64) k_q_select(Region *__restrict__ blk, Regio
         const Region k = blk[b];
         t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
         for (int q = 0; q < 4; ++q) t.score[q] = score[q];
+    }
+    if (chk && status) {
+        // tuning q_hist = 3: the reference-order score of every quadrant has to lie inside the interval k_q_decide
+        // derived from the byte histograms, and a decision it would have taken has to be this argmax
+        bool bad = false;
+        for (int q = 0; q < 4; ++q) bad = bad || !(score[q] >= chk[b * 9 + q] && score[q] <= chk[b * 9 + 4 + q]);
+        if (chk[b * 9 + 8] >= 0.0 && (int)chk[b * 9 + 8] != arg) bad = true;
+        if (bad) atomicOr(status, (uint32_t)UWIE_STATUS_QTREE_BOUNDS);
     }
     q_descend(blk, regs, edges, b, arg, min_size);
 }
@@ -964,12 +984,13 @@ __device__ uint32_t tail_hysteresis(uint16_t *st, int rows, int cols, int lane)
 __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
                                                            const uint8_t *__restrict__ gray, Region *__restrict__ blk, int H,
                                                            int W, int level0, int min_size, TraceRec *__restrict__ trace,
-                                                           float *__restrict__ A, int use_hist)
+                                                           float *__restrict__ A, int use_hist, uint32_t *__restrict__ status)
 {
 #ifdef UWIE_TAIL_PROF
     const bool hist_mode = use_hist;  // (profiling build: the trace carries phase times, not scores)
 #else
     const bool hist_mode = use_hist && !trace;  // (recorded scores are the exact ones)
+    const bool check_mode = hist_mode && use_hist == 2;  // tuning q_hist = 3: intervals AND exact scores, compared below
 #endif
     extern __shared__ __attribute__((aligned(16))) uint8_t tail_lds[];
     __shared__ double s_q[4];
@@ -978,6 +999,7 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
     __shared__ uint32_t s_edges[4];
     __shared__ double s_ilo[4], s_ihi[4], s_sv[4][6];
     __shared__ int s_dec;
+    __shared__ double s_clo[4], s_chi[4];  // (check mode) the level's four intervals with the edge term
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qd = wid / kTailSub, sw = wid % kTailSub, ql = sw * 64 + lane;  // quadrant, wavefront and lane inside it
     uint8_t *pix = tail_lds + (size_t)qd * kTailQuadBytes;
@@ -1109,6 +1131,8 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
                     const double t4 = (double)s_edges[q] / ((double)rows4[q] * (double)cols4[q]);
                     lo[q] = s_ilo[q] - t4;
                     hi[q] = s_ihi[q] - t4;
+                    s_clo[q] = lo[q];
+                    s_chi[q] = hi[q];
                 }
                 int best = 0;
                 for (int q = 1; q < 4; ++q)
@@ -1120,7 +1144,7 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
             }
             __syncthreads();
             arg = s_dec & 255;
-            sure = (s_dec >> 8) != 0;
+            sure = (s_dec >> 8) != 0 && !check_mode;
         }
         if (!sure) {  // (workgroup-uniform) the exact NumPy-order sums: the RGB bytes come in again
             __syncthreads();
@@ -1172,6 +1196,12 @@ __global__ void __launch_bounds__(256 * kTailSub) k_q_tail(const uint8_t *__rest
             arg = 0;
             for (int q = 1; q < 4; ++q)
                 if (score[q] > score[arg]) arg = q;  // np.argmax: first maximum
+            if (check_mode && threadIdx.x == 0 && status) {  // (see k_q_select)
+                bool bad = false;
+                for (int q = 0; q < 4; ++q) bad = bad || !(score[q] >= s_clo[q] && score[q] <= s_chi[q]);
+                if ((s_dec >> 8) != 0 && (s_dec & 255) != arg) bad = true;
+                if (bad) atomicOr(status, (uint32_t)UWIE_STATUS_QTREE_BOUNDS);
+            }
             if (trace && threadIdx.x == 0) {
                 TraceRec &t = trace[b * kMaxLevels + level];
                 t.y0 = k.y0; t.x0 = k.x0; t.rows = k.rows; t.cols = k.cols;
@@ -1233,6 +1263,7 @@ LevelBufs carve_level(Carver &c, Shape s)
     L.edges = c.take<uint32_t>(nreg);
     L.hist = c.take<uint32_t>(nreg * 768);
     L.skip = c.take<uint8_t>(s.B);
+    L.chk = c.take<double>((size_t)s.B * 9);
     return L;
 }
 
@@ -1332,7 +1363,8 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
             int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0);
             if (rc != UWIE_OK) return rc;
             UWIE_LAUNCH(k_q_decide, dim3(B), dim3(256), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
-                        (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip, canny_strong_flags(canny_ws, s));
+                        (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip, canny_strong_flags(canny_ws, s),
+                        tune().q_hist == 3 ? L.chk : (double *)nullptr);
             UWIE_LAUNCH_CHECK();
         }
         const uint8_t *skip = use_hist ? L.skip : nullptr;
@@ -1353,7 +1385,8 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
             if (rc != UWIE_OK) return rc;
         }
         UWIE_LAUNCH(k_q_select, dim3(B), dim3(64), 0, st, L.blk, L.regs, (const float *)L.csum, (const float *)L.csum_var,
-                           maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace, skip);
+                           maxChunks, L.edges, B, level, min_size, (TraceRec *)d_trace, skip,
+                           use_hist && tune().q_hist == 3 ? (const double *)L.chk : (const double *)nullptr, ctx ? ctx->d_status : nullptr);
         UWIE_LAUNCH_CHECK();
         rmax = qr;
         cmax = qc;
@@ -1368,7 +1401,7 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         }
     }
     UWIE_LAUNCH(k_q_tail, dim3(B), dim3(256 * kTailSub), 4 * kTailQuadBytes, st, d_in, d_kind, d_gray, L.blk, s.H, s.W, level, min_size,
-                (TraceRec *)d_trace, d_A, tune().q_hist == 1 ? 1 : 0);
+                (TraceRec *)d_trace, d_A, tune().q_hist == 1 ? 1 : tune().q_hist == 3 ? 2 : 0, ctx ? ctx->d_status : nullptr);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
