@@ -15,15 +15,30 @@ namespace uwie {
 namespace {
 
 // ---- sources for the row pass.  Raw = what is staged in LDS per pixel; plane(raw, w) = the value of plane w.
+typedef double2 __attribute__((aligned(8))) gdouble2_a8;
+typedef float4 __attribute__((aligned(4))) gfloat4_a4;
+typedef uint32_t __attribute__((aligned(1))) gu32_a1;
+
 struct SrcPlanes1 {
     const double *p;
     int H, W;
     static constexpr int NP = 1;
+    static constexpr int CH = 16;  // columns per lane and trip in k_box_rows_lane
     struct Raw {
         double v;
     };
     __device__ __forceinline__ Raw load(int b, int y, int x) const { return Raw{p[((size_t)b * H + y) * W + x]}; }
     __device__ static __forceinline__ double plane(const Raw &r, int, const double *) { return r.v; }
+    template <int N>
+    __device__ __forceinline__ void load_run(int b, int y, int x, Raw (&r)[N]) const  // N consecutive columns from x
+    {
+        const double *q = p + ((size_t)b * H + y) * W + x;
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {
+            const gdouble2_a8 v = *reinterpret_cast<const gdouble2_a8 *>(q + i);
+            r[i].v = v.x; r[i + 1].v = v.y;
+        }
+    }
 };
 struct SrcPlanes2 {
     const double *p0, *p1;
@@ -38,6 +53,18 @@ struct SrcPlanes2 {
         return Raw{p0[i], p1[i]};
     }
     __device__ static __forceinline__ double plane(const Raw &r, int w, const double *) { return w == 0 ? r.a : r.b; }
+    static constexpr int CH = 8;
+    template <int N>
+    __device__ __forceinline__ void load_run(int b, int y, int x, Raw (&r)[N]) const
+    {
+        const size_t i0 = ((size_t)b * H + y) * W + x;
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {
+            const gdouble2_a8 va = *reinterpret_cast<const gdouble2_a8 *>(p0 + i0 + i), vb = *reinterpret_cast<const gdouble2_a8 *>(p1 + i0 + i);
+            r[i].a = va.x; r[i + 1].a = va.y;
+            r[i].b = vb.x; r[i + 1].b = vb.y;
+        }
+    }
 };
 // I = gray/255 (float64), p = t0 (.astype(float64): float32 from the u8-derived frame, float64 for a float64 image on the
 // dict surface); planes I, p, I*p, I*I (six_stadigy.py:28-36)
@@ -60,6 +87,27 @@ struct SrcGuideT {
     {
         const double I = ilut[r.g], p = (double)r.t0;
         return w == 0 ? I : w == 1 ? p : w == 2 ? I * p : I * I;
+    }
+    static constexpr int CH = sizeof(TP) == 4 ? 16 : 8;
+    template <int N>
+    __device__ __forceinline__ void load_run(int b, int y, int x, Raw (&r)[N]) const
+    {
+        const size_t i0 = ((size_t)b * H + y) * W + x;
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const uint32_t g4 = *reinterpret_cast<const gu32_a1 *>(gray + i0 + i);
+            r[i].g = g4 & 255u; r[i + 1].g = (g4 >> 8) & 255u; r[i + 2].g = (g4 >> 16) & 255u; r[i + 3].g = g4 >> 24;
+            if constexpr (sizeof(TP) == 4) {
+                const gfloat4_a4 v = *reinterpret_cast<const gfloat4_a4 *>(t0 + i0 + i);
+                r[i].t0 = v.x; r[i + 1].t0 = v.y; r[i + 2].t0 = v.z; r[i + 3].t0 = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const gdouble2_a8 v = *reinterpret_cast<const gdouble2_a8 *>(t0 + i0 + i + j);
+                    r[i + j].t0 = v.x; r[i + j + 1].t0 = v.y;
+                }
+            }
+        }
     }
 };
 using SrcGuide = SrcGuideT<float>;
@@ -121,6 +169,110 @@ __global__ void __launch_bounds__(64 * Src::NP) k_box_rows(Src src, double *__re
     }
 }
 
+// Row pass, round 4: the same literal chain, one LANE per row and every plane of the row in that lane.
+// k_box_rows above stages 64 x 16 tiles through LDS for a workgroup of NP wavefronts: 240 barrier-separated tiles of a 4K row,
+// each a global round trip (4.0 + 2.6 ms of the exact-order filter's 10.0 at 4K x 16).  Here a workgroup is ONE wavefront that
+// owns 64 rows: a lane reads its row's entering and leaving elements CH columns at a time (16-byte loads, the next trip's
+// issued before this trip's arithmetic), keeps the NP running sums in registers (NP independent dependency chains per lane)
+// and hands the trip's NP x 64 x 16 results through an 8.5 KB LDS tile so that they leave as whole 128-byte lines (eight rows
+// per store instruction; stored lane by lane they were 64 partial lines per instruction and the pass ran at 1.7 TB/s).  The
+// tile is wavefront-private: no barrier anywhere.  grid (ceil(H / 64), B), block 64; trips are aligned to 16 columns.
+__device__ __forceinline__ void gwave_lds_sync()  // LDS executes one wavefront's instructions in order: a compiler fence is all
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kLaneOT = 17;  // tile row stride in doubles: lane = row writes hit 64 different bank pairs
+
+template <class Src>
+__global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restrict__ out, size_t plane_stride, int k)
+{
+    constexpr int NP = Src::NP, CH = Src::CH;  // CH = 8 or 16 columns per trip
+    using Raw = typename Src::Raw;
+    __shared__ double ilut[256];
+    __shared__ double otile[64 * kLaneOT];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
+    __syncthreads();
+    const int b = blockIdx.y, H = src.H, W = src.W, a = k / 2, y0 = (int)blockIdx.x * 64;
+    const int y = min(y0 + lane, H - 1);  // (rows past the end repeat the last one and store nothing)
+    const bool live = y0 + lane < H;
+    double s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = 0.0;
+    for (int j = 0; j < k; ++j) {  // E[0] + ... + E[k-1], left to right (BORDER_REFLECT_101, anchor a)
+        const Raw r = src.load(b, y, reflect101(j - a, W));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] += Src::plane(r, p, ilut);
+    }
+    double *o[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        o[p] = out + (size_t)p * plane_stride + ((size_t)b * H + y) * W;
+        if (live) o[p][0] = s[p];
+    }
+    // columns col0 .. col0 + CH - 1: out[col] = (s += E[col - 1 + k] - E[col - 1]); E[j] = src[reflect101(j - a)]
+    // interior trips: neither run touches the border extension
+    auto interior = [&](int col0) { return col0 - 1 - a >= 0 && col0 - 1 + k - a + CH <= W && col0 + CH <= W; };
+    Raw lead_nx[CH], trail_nx[CH];
+    bool have_nx = false;
+    // the transposed side of the tile: lane -> row i * (64 / LPR) + lane / LPR, column pair (lane % LPR) * 2
+    constexpr int LPR = CH / 2, RPI = 64 / LPR;
+    const int t_row = lane / LPR, t_col = (lane % LPR) * 2;
+    for (int col0 = 0; col0 < W; col0 += CH) {
+        if (have_nx) {
+            Raw lead[CH], trail[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { lead[c] = lead_nx[c]; trail[c] = trail_nx[c]; }
+            have_nx = interior(col0 + CH);
+            if (have_nx) {
+                src.template load_run<CH>(b, y, col0 + CH - 1 + k - a, lead_nx);
+                src.template load_run<CH>(b, y, col0 + CH - 1 - a, trail_nx);
+            }
+            double res[NP][CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    s[p] += Src::plane(lead[c], p, ilut) - Src::plane(trail[c], p, ilut);
+                    res[p][c] = s[p];
+                }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) otile[lane * kLaneOT + c] = res[p][c];
+                gwave_lds_sync();
+                double *op = out + (size_t)p * plane_stride + ((size_t)b * H + y0) * W + col0 + t_col;
+#pragma unroll
+                for (int i = 0; i < LPR; ++i) {
+                    const int row = i * RPI + t_row;
+                    const double v0 = otile[row * kLaneOT + t_col], v1 = otile[row * kLaneOT + t_col + 1];
+                    if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
+                }
+                gwave_lds_sync();
+            }
+        } else {  // a trip that touches the left / right border, or the ragged end of the row: element by element
+            for (int c = 0; c < CH && col0 + c < W; ++c) {
+                const int col = col0 + c;
+                if (col == 0) continue;  // (stored above)
+                const Raw le = src.load(b, y, reflect101(col - 1 + k - a, W)), tr = src.load(b, y, reflect101(col - 1 - a, W));
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    s[p] += Src::plane(le, p, ilut) - Src::plane(tr, p, ilut);
+                    if (live) o[p][col] = s[p];
+                }
+            }
+            have_nx = interior(col0 + CH);
+            if (have_nx) {
+                src.template load_run<CH>(b, y, col0 + CH - 1 + k - a, lead_nx);
+                src.template load_run<CH>(b, y, col0 + CH - 1 - a, trail_nx);
+            }
+        }
+    }
+}
+
 // ---- epilogues of the column pass
 struct EpiStore1 {
     double *dst;
@@ -172,16 +324,44 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
 #pragma unroll
         for (int p = 0; p < NP; ++p) sum[p] += base[p * plane_stride + r];
     }
-    for (int y = 0; y < H; ++y) {
-        const size_t rp = (size_t)reflect101(y + k - 1 - a, H) * W, rm = (size_t)reflect101(y - a, H) * W;
+    // rows [y_lo, y_hi): neither the entering nor the leaving row is in the border extension; there the walk goes kColU rows per
+    // trip with every load of the trip issued before its arithmetic (the sums do not feed the addresses)
+    constexpr int kColU = 4;
+    const int y_lo = min(a, H), y_hi = max(y_lo, H - (k - 1 - a));
+    int y = 0;
+    auto one_row = [&](int yy) {
+        const size_t rp = (size_t)reflect101(yy + k - 1 - a, H) * W, rm = (size_t)reflect101(yy - a, H) * W;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const double s0 = sum[p] + base[p * plane_stride + rp];
             mean[p] = s0 * scale;
             sum[p] = s0 - base[p * plane_stride + rm];
         }
-        epi(ilut, ((size_t)b * H + y) * W + x, mean);
+        epi(ilut, ((size_t)b * H + yy) * W + x, mean);
+    };
+    for (; y < y_lo; ++y) one_row(y);
+    for (; y + kColU <= y_hi; y += kColU) {
+        double in[kColU][NP], ou[kColU][NP];
+        const double *pin = base + (size_t)(y + k - 1 - a) * W, *pou = base + (size_t)(y - a) * W;
+#pragma unroll
+        for (int u = 0; u < kColU; ++u)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                in[u][p] = pin[p * plane_stride + (size_t)u * W];
+                ou[u][p] = pou[p * plane_stride + (size_t)u * W];
+            }
+#pragma unroll
+        for (int u = 0; u < kColU; ++u) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const double s0 = sum[p] + in[u][p];
+                mean[p] = s0 * scale;
+                sum[p] = s0 - ou[u][p];
+            }
+            epi(ilut, ((size_t)b * H + y + u) * W + x, mean);
+        }
     }
+    for (; y < H; ++y) one_row(y);
 }
 
 // first half of estimate_transmission: six_stadigy.py:170-174 / enhancement_strategies.py:221-225
@@ -245,7 +425,7 @@ int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, vo
     Carver c(ws);
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n);
-    UWIE_LAUNCH(k_box_rows<SrcPlanes1>, dim3(cdiv(s.H, kTR), s.B), dim3(64), 0, st, SrcPlanes1{d_src, s.H, s.W}, rs, n, k);
+    UWIE_LAUNCH(k_box_rows_lane<SrcPlanes1>, dim3(cdiv(s.H, 64), s.B), dim3(64), 0, st, SrcPlanes1{d_src, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiStore1>, dim3(cdiv((long long)s.B * s.W, 64)), dim3(64), 0, st, rs, n,
                        EpiStore1{d_dst}, s.B, s.H, s.W, k);
@@ -268,11 +448,11 @@ static int launch_guided_t(const uint8_t *d_gray, const TP *d_t0, Shape s, int k
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
     const dim3 grows(cdiv(s.H, kTR), s.B), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
-    UWIE_LAUNCH(k_box_rows<SrcGuideT<TP>>, grows, dim3(256), 0, st, SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k);
+    UWIE_LAUNCH(k_box_rows_lane<SrcGuideT<TP>>, grows, blk, 0, st, SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_rows<SrcPlanes2>, grows, dim3(128), 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, k);
+    UWIE_LAUNCH(k_box_rows_lane<SrcPlanes2>, grows, blk, 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, k);
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
     UWIE_LAUNCH_CHECK();
