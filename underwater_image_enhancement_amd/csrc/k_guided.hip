@@ -22,6 +22,7 @@ typedef uint32_t __attribute__((aligned(1))) gu32_a1;
 struct SrcPlanes1 {
     const double *p;
     int H, W;
+    static constexpr const char *kName = "k_box_rows_lane<SrcPlanes1>";
     static constexpr int NP = 1;
     static constexpr int CH = 16;  // columns per lane and trip in k_box_rows_lane
     struct Raw {
@@ -43,6 +44,7 @@ struct SrcPlanes1 {
 struct SrcPlanes2 {
     const double *p0, *p1;
     int H, W;
+    static constexpr const char *kName = "k_box_rows_lane<SrcPlanes2>";
     static constexpr int NP = 2;
     struct Raw {
         double a, b;
@@ -89,6 +91,7 @@ struct SrcGuideT {
         return w == 0 ? I : w == 1 ? p : w == 2 ? I * p : I * I;
     }
     static constexpr int CH = sizeof(TP) == 4 ? 16 : 8;
+    static constexpr const char *kName = "k_box_rows_lane<SrcGuideT>";
     template <int N>
     __device__ __forceinline__ void load_run(int b, int y, int x, Raw (&r)[N]) const
     {
@@ -186,16 +189,21 @@ __device__ __forceinline__ void gwave_lds_sync()  // LDS executes one wavefront'
 
 constexpr int kLaneOT = 17;  // tile row stride in doubles: lane = row writes hit 64 different bank pairs
 
-template <class Src>
-__global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restrict__ out, size_t plane_stride, int k)
+// K > 0: the window is known at compile time and no leaving element is loaded at all -- E[col - 1] entered the window K
+// columns earlier, so the lane keeps its last ceil(K / CH) runs of entering elements in registers.  K = 0: any window, the
+// leaving run is loaded like the entering one (it hits in L2).
+template <class Src, int K>
+__global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restrict__ out, size_t plane_stride, int k_rt)
 {
     constexpr int NP = Src::NP, CH = Src::CH;  // CH = 8 or 16 columns per trip
+    constexpr int D = K > 0 ? (K + CH - 1) / CH : 1;  // runs of history in front of the current one
     using Raw = typename Src::Raw;
     __shared__ double ilut[256];
-    __shared__ double otile[64 * kLaneOT];
+    __shared__ double otile[NP][64 * kLaneOT];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
     __syncthreads();
+    const int k = K > 0 ? K : k_rt;
     const int b = blockIdx.y, H = src.H, W = src.W, a = k / 2, y0 = (int)blockIdx.x * 64;
     const int y = min(y0 + lane, H - 1);  // (rows past the end repeat the last one and store nothing)
     const bool live = y0 + lane < H;
@@ -213,47 +221,22 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
         o[p] = out + (size_t)p * plane_stride + ((size_t)b * H + y) * W;
         if (live) o[p][0] = s[p];
     }
-    // columns col0 .. col0 + CH - 1: out[col] = (s += E[col - 1 + k] - E[col - 1]); E[j] = src[reflect101(j - a)]
-    // interior trips: neither run touches the border extension
-    auto interior = [&](int col0) { return col0 - 1 - a >= 0 && col0 - 1 + k - a + CH <= W && col0 + CH <= W; };
-    Raw lead_nx[CH], trail_nx[CH];
-    bool have_nx = false;
+    // columns col0 .. col0 + CH - 1: out[col] = (s += E[col - 1 + k] - E[col - 1]); E[j] = src[reflect101(j - a)], so the
+    // entering run starts at source column xe(col0) = col0 - 1 + k - a and the leaving one at col0 - 1 - a.
+    // hist[D * CH + c] is the entering element of column col0 + c; hist[i] is source column xe(col0) + i - D * CH.
+    // interior trips: nothing the trip (or its history) reads is in the border extension
+    const int xe0 = k - 1 - a;
+    auto interior = [&](int col0) {
+        const int first = K > 0 ? col0 + xe0 - D * CH : col0 - 1 - a;
+        return first >= 0 && col0 + xe0 + CH <= W && col0 + CH <= W;
+    };
+    Raw hist[(D + 1) * CH], nx[CH];
+    bool primed = false, have_nx = false;
     // the transposed side of the tile: lane -> row i * (64 / LPR) + lane / LPR, column pair (lane % LPR) * 2
     constexpr int LPR = CH / 2, RPI = 64 / LPR;
     const int t_row = lane / LPR, t_col = (lane % LPR) * 2;
     for (int col0 = 0; col0 < W; col0 += CH) {
-        if (have_nx) {
-            Raw lead[CH], trail[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) { lead[c] = lead_nx[c]; trail[c] = trail_nx[c]; }
-            have_nx = interior(col0 + CH);
-            if (have_nx) {
-                src.template load_run<CH>(b, y, col0 + CH - 1 + k - a, lead_nx);
-                src.template load_run<CH>(b, y, col0 + CH - 1 - a, trail_nx);
-            }
-            double res[NP][CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    s[p] += Src::plane(lead[c], p, ilut) - Src::plane(trail[c], p, ilut);
-                    res[p][c] = s[p];
-                }
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c) otile[lane * kLaneOT + c] = res[p][c];
-                gwave_lds_sync();
-                double *op = out + (size_t)p * plane_stride + ((size_t)b * H + y0) * W + col0 + t_col;
-#pragma unroll
-                for (int i = 0; i < LPR; ++i) {
-                    const int row = i * RPI + t_row;
-                    const double v0 = otile[row * kLaneOT + t_col], v1 = otile[row * kLaneOT + t_col + 1];
-                    if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
-                }
-                gwave_lds_sync();
-            }
-        } else {  // a trip that touches the left / right border, or the ragged end of the row: element by element
+        if (!interior(col0)) {  // a trip that touches the left / right border, or the ragged end of the row: element by element
             for (int c = 0; c < CH && col0 + c < W; ++c) {
                 const int col = col0 + c;
                 if (col == 0) continue;  // (stored above)
@@ -264,25 +247,181 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
                     if (live) o[p][col] = s[p];
                 }
             }
-            have_nx = interior(col0 + CH);
-            if (have_nx) {
-                src.template load_run<CH>(b, y, col0 + CH - 1 + k - a, lead_nx);
-                src.template load_run<CH>(b, y, col0 + CH - 1 - a, trail_nx);
+            primed = false;
+            have_nx = false;
+            continue;
+        }
+        if (K > 0 && !primed) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                Raw tmp[CH];
+                src.template load_run<CH>(b, y, col0 + xe0 - (D - d) * CH, tmp);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) hist[d * CH + c] = tmp[c];
+            }
+            primed = true;
+        }
+        if (!have_nx) src.template load_run<CH>(b, y, col0 + xe0, nx);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) hist[D * CH + c] = nx[c];
+        if (K == 0) {
+            Raw tmp[CH];
+            src.template load_run<CH>(b, y, col0 - 1 - a, tmp);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) hist[c] = tmp[c];  // D = 1: hist[0 .. CH) is the leaving run
+        }
+        have_nx = interior(col0 + CH);
+        if (have_nx) src.template load_run<CH>(b, y, col0 + CH + xe0, nx);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const Raw &le = hist[D * CH + c], &tr = hist[K > 0 ? D * CH + c - K : c];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                s[p] += Src::plane(le, p, ilut) - Src::plane(tr, p, ilut);
+                otile[p][lane * kLaneOT + c] = s[p];
             }
         }
+        if (K > 0) {
+#pragma unroll
+            for (int i = 0; i < D * CH; ++i) hist[i] = hist[i + CH];
+        }
+        gwave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double *op = out + (size_t)p * plane_stride + ((size_t)b * H + y0) * W + col0 + t_col;
+#pragma unroll
+            for (int i = 0; i < LPR; ++i) {
+                const int row = i * RPI + t_row;
+                const double v0 = otile[p][row * kLaneOT + t_col], v1 = otile[p][row * kLaneOT + t_col + 1];
+                if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
+            }
+        }
+        gwave_lds_sync();
+    }
+}
+
+template <class Src>
+static void launch_rows_lane(Src src, double *rs, size_t n, int k, int B, hipStream_t st)
+{
+    const dim3 grid(cdiv(src.H, 64), B), blk(64);
+    UWIE_PROF(Src::kName, st);
+    if (k == 15) hipLaunchKernelGGL((k_box_rows_lane<Src, 15>), grid, blk, 0, st, src, rs, n, k);
+    else hipLaunchKernelGGL((k_box_rows_lane<Src, 0>), grid, blk, 0, st, src, rs, n, k);
+}
+
+// Row pass over float64 PLANES (the second box filter's a and b, and uwie_box_filter_f64), windows of at most 16 columns: the
+// lane kernel above reads such a plane in 16-byte pieces, 64 lines per instruction, and every line comes back for the next
+// trip and again when its elements leave (6.7 ms at 4K x 64 against 5.4 for the four-plane pass that moves more).  Here one
+// wavefront owns 64 rows of ONE plane (blockIdx.z) and a trip's entering run arrives as whole lines -- eight rows per load
+// instruction, the next trip's issued before this trip's arithmetic -- into a 32-column LDS ring per row; the ring still holds
+// the previous run, so the leaving elements (k <= 16 columns back) are read from it and never loaded.  Results leave through
+// the same kind of tile as above.  25.6 KB of LDS per wavefront; wavefront-private, no barrier.
+constexpr int kRingW = 32, kRingS = kRingW + 1;  // ring columns per row and its row stride in doubles
+
+__global__ void __launch_bounds__(64) k_box_rows_ring(const double *__restrict__ p0, const double *__restrict__ p1, int H, int W,
+                                                      double *__restrict__ out, size_t plane_stride, int k)
+{
+    constexpr int CH = 16, LPR = CH / 2, RPI = 64 / LPR;
+    __shared__ double ring[64 * kRingS];
+    __shared__ double otile[64 * kLaneOT];
+    const int lane = threadIdx.x, b = blockIdx.y, a = k / 2, y0 = (int)blockIdx.x * 64;
+    const double *src = (blockIdx.z ? p1 : p0) + (size_t)b * H * W;
+    out += (size_t)blockIdx.z * plane_stride + (size_t)b * H * W;
+    const int y = min(y0 + lane, H - 1);  // (rows past the end repeat the last one and store nothing)
+    const bool live = y0 + lane < H;
+    const double *srow = src + (size_t)y * W;
+    double *orow = out + (size_t)y * W;
+    double s = 0.0;
+    for (int j = 0; j < k; ++j) s += srow[reflect101(j - a, W)];  // E[0] + ... + E[k-1], left to right
+    if (live) orow[0] = s;
+    const int xe0 = k - 1 - a;  // the entering run of columns col0 .. col0 + 15 starts at source column col0 + xe0
+    auto interior = [&](int col0) { return col0 + xe0 - CH >= 0 && col0 + xe0 + CH <= W && col0 + CH <= W; };
+    const int t_row = lane / LPR, t_col = (lane % LPR) * 2;
+    // the coalesced side: instruction i covers rows i * 8 + lane / 8 (clamped into the frame), two columns per lane
+    auto load_run = [&](int x, gdouble2_a8 (&r)[LPR]) {
+#pragma unroll
+        for (int i = 0; i < LPR; ++i)
+            r[i] = *reinterpret_cast<const gdouble2_a8 *>(src + (size_t)min(y0 + i * RPI + t_row, H - 1) * W + x + t_col);
+    };
+    auto put_run = [&](int slot, const gdouble2_a8 (&r)[LPR]) {
+#pragma unroll
+        for (int i = 0; i < LPR; ++i) {
+            double *q = ring + (i * RPI + t_row) * kRingS + slot * CH + t_col;
+            q[0] = r[i].x;
+            q[1] = r[i].y;
+        }
+    };
+    gdouble2_a8 nx[LPR];
+    bool primed = false, have_nx = false;
+    int slot = 0;
+    for (int col0 = 0; col0 < W; col0 += CH) {
+        if (!interior(col0)) {  // a trip that touches the left / right border, or the ragged end of the row: element by element
+            for (int c = 0; c < CH && col0 + c < W; ++c) {
+                const int col = col0 + c;
+                if (col == 0) continue;  // (stored above)
+                s += srow[reflect101(col - 1 + k - a, W)] - srow[reflect101(col - 1 - a, W)];
+                if (live) orow[col] = s;
+            }
+            primed = false;
+            have_nx = false;
+            continue;
+        }
+        slot ^= 1;
+        if (!primed) {  // the run before this trip's: its elements leave during this trip
+            gdouble2_a8 pv[LPR];
+            load_run(col0 + xe0 - CH, pv);
+            put_run(slot ^ 1, pv);
+            primed = true;
+        }
+        if (!have_nx) load_run(col0 + xe0, nx);
+        put_run(slot, nx);
+        gwave_lds_sync();
+        have_nx = interior(col0 + CH);
+        if (have_nx) load_run(col0 + CH + xe0, nx);
+        const double *rrow = ring + lane * kRingS;
+        const int le0 = slot * CH, tr0 = slot * CH - k + kRingW;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            s += rrow[le0 + c] - rrow[(tr0 + c) & (kRingW - 1)];
+            otile[lane * kLaneOT + c] = s;
+        }
+        gwave_lds_sync();
+        double *op = out + (size_t)y0 * W + col0 + t_col;
+#pragma unroll
+        for (int i = 0; i < LPR; ++i) {
+            const int row = i * RPI + t_row;
+            const double v0 = otile[row * kLaneOT + t_col], v1 = otile[row * kLaneOT + t_col + 1];
+            if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
+        }
+        gwave_lds_sync();
+    }
+}
+
+// rows of one or two float64 planes: the ring kernel when the window fits it, the lane kernel otherwise
+static void launch_rows_planes(const double *p0, const double *p1, Shape s, double *rs, size_t n, int k, hipStream_t st)
+{
+    if (k <= 16 && s.W >= 2) {
+        UWIE_PROF(p1 ? "k_box_rows_ring x2" : "k_box_rows_ring", st);
+        hipLaunchKernelGGL(k_box_rows_ring, dim3(cdiv(s.H, 64), s.B, p1 ? 2 : 1), dim3(64), 0, st, p0, p1, s.H, s.W, rs, n, k);
+    } else if (p1) {
+        launch_rows_lane(SrcPlanes2{p0, p1, s.H, s.W}, rs, n, k, s.B, st);
+    } else {
+        launch_rows_lane(SrcPlanes1{p0, s.H, s.W}, rs, n, k, s.B, st);
     }
 }
 
 // ---- epilogues of the column pass
 struct EpiStore1 {
     double *dst;
-    static constexpr int NP = 1;
+    static constexpr const char *kName = "k_box_cols<EpiStore1>";
+    static constexpr int NP = 1, U = 7;  // U: rows per load batch of the ring walk in k_box_cols
     __device__ __forceinline__ void operator()(const double *, size_t i, const double *m) const { dst[i] = m[0]; }
 };
 struct EpiAB {  // a = cov/(var+eps), b = mean_p - a*mean_I (six_stadigy.py:34-40)
     double *a, *b;
     double eps;
-    static constexpr int NP = 4;
+    static constexpr const char *kName = "k_box_cols<EpiAB>";
+    static constexpr int NP = 4, U = 2;
     __device__ __forceinline__ void operator()(const double *, size_t i, const double *m) const
     {
         const double cov = m[2] - m[0] * m[1];
@@ -295,7 +434,8 @@ struct EpiAB {  // a = cov/(var+eps), b = mean_p - a*mean_I (six_stadigy.py:34-4
 struct EpiQ {  // q = mean_a*I + mean_b, then np.clip(q, 0.1, 1.0) (six_stadigy.py:45,180)
     const uint8_t *gray;
     double *t;
-    static constexpr int NP = 2;
+    static constexpr const char *kName = "k_box_cols<EpiQ>";
+    static constexpr int NP = 2, U = 7;
     __device__ __forceinline__ void operator()(const double *ilut, size_t i, const double *m) const
     {
         const double q = m[0] * ilut[gray[i]] + m[1];
@@ -303,9 +443,12 @@ struct EpiQ {  // q = mean_a*I + mean_b, then np.clip(q, 0.1, 1.0) (six_stadigy.
     }
 };
 
-template <class Epi>
+// K > 0: the window is known at compile time and the leaving row is never loaded: what enters at row step y leaves at step
+// y + K - 1, so the lane keeps its last K - 1 entering values of every plane in a register ring (the ring index is the unrolled
+// step).  With loads, the leaving rows of a 4K x 64 batch are 110 MB behind the entering ones: out of L2 again.
+template <class Epi, int K>
 __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, size_t plane_stride, Epi epi, int B, int H,
-                                                 int W, int k)
+                                                 int W, int k_rt)
 {
     constexpr int NP = Epi::NP;
     __shared__ double ilut[256];
@@ -313,6 +456,7 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
     __syncthreads();
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= B * W) return;
+    const int k = K > 0 ? K : k_rt;
     const int b = col / W, x = col % W, a = k / 2;
     const double scale = 1.0 / ((double)k * (double)k);
     const double *base = rs + (size_t)b * H * W + x;
@@ -324,9 +468,7 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
 #pragma unroll
         for (int p = 0; p < NP; ++p) sum[p] += base[p * plane_stride + r];
     }
-    // rows [y_lo, y_hi): neither the entering nor the leaving row is in the border extension; there the walk goes kColU rows per
-    // trip with every load of the trip issued before its arithmetic (the sums do not feed the addresses)
-    constexpr int kColU = 4;
+    // rows [y_lo, y_hi): neither the entering nor the leaving row is in the border extension
     const int y_lo = min(a, H), y_hi = max(y_lo, H - (k - 1 - a));
     int y = 0;
     auto one_row = [&](int yy) {
@@ -340,28 +482,82 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
         epi(ilut, ((size_t)b * H + yy) * W + x, mean);
     };
     for (; y < y_lo; ++y) one_row(y);
-    for (; y + kColU <= y_hi; y += kColU) {
-        double in[kColU][NP], ou[kColU][NP];
-        const double *pin = base + (size_t)(y + k - 1 - a) * W, *pou = base + (size_t)(y - a) * W;
+    if constexpr (K > 1) {
+        constexpr int R = K - 1, U = Epi::U, NB = R / U;  // ring entries; entering rows are loaded U at a time, one batch ahead
+        static_assert(R % U == 0, "the unrolled period is whole batches");
+        if (y + R <= y_hi) {
+            double ring[R][NP], in[U][NP];
 #pragma unroll
-        for (int u = 0; u < kColU; ++u)
+            for (int u = 0; u < R; ++u)  // the rows that leave at steps y .. y + R - 1: y - a + u
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                in[u][p] = pin[p * plane_stride + (size_t)u * W];
-                ou[u][p] = pou[p * plane_stride + (size_t)u * W];
+                for (int p = 0; p < NP; ++p) ring[u][p] = base[p * plane_stride + (size_t)(y - a + u) * W];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) in[u][p] = base[p * plane_stride + (size_t)(y + K - 1 - a + u) * W];
+            for (; y + R <= y_hi; y += R) {
+#pragma unroll
+                for (int h = 0; h < NB; ++h) {
+                    double nx[U][NP];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {  // (past the last period: any valid row, the values are dropped)
+                        const size_t r = (size_t)min(y + (h + 1) * U + K - 1 - a + u, H - 1) * W;
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) nx[u][p] = base[p * plane_stride + r];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const double s0 = sum[p] + in[u][p];
+                            mean[p] = s0 * scale;
+                            sum[p] = s0 - ring[h * U + u][p];
+                            ring[h * U + u][p] = in[u][p];
+                        }
+                        epi(ilut, ((size_t)b * H + y + h * U + u) * W + x, mean);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) in[u][p] = nx[u][p];
+                    __builtin_amdgcn_sched_barrier(0);  // (or the scheduler lifts every batch's loads to the top of the period)
+                }
             }
+        }
+    } else {
+        constexpr int kColU = 4;  // rows per trip, every load of the trip issued before its arithmetic
+        for (; y + kColU <= y_hi; y += kColU) {
+            double in[kColU][NP], ou[kColU][NP];
+            const double *pin = base + (size_t)(y + k - 1 - a) * W, *pou = base + (size_t)(y - a) * W;
 #pragma unroll
-        for (int u = 0; u < kColU; ++u) {
+            for (int u = 0; u < kColU; ++u)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const double s0 = sum[p] + in[u][p];
-                mean[p] = s0 * scale;
-                sum[p] = s0 - ou[u][p];
+                for (int p = 0; p < NP; ++p) {
+                    in[u][p] = pin[p * plane_stride + (size_t)u * W];
+                    ou[u][p] = pou[p * plane_stride + (size_t)u * W];
+                }
+#pragma unroll
+            for (int u = 0; u < kColU; ++u) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const double s0 = sum[p] + in[u][p];
+                    mean[p] = s0 * scale;
+                    sum[p] = s0 - ou[u][p];
+                }
+                epi(ilut, ((size_t)b * H + y + u) * W + x, mean);
             }
-            epi(ilut, ((size_t)b * H + y + u) * W + x, mean);
         }
     }
     for (; y < H; ++y) one_row(y);
+}
+
+template <class Epi>
+static void launch_cols(const double *rs, size_t n, Epi epi, Shape s, int k, hipStream_t st)
+{
+    const dim3 grid(cdiv((long long)s.B * s.W, 64)), blk(64);
+    UWIE_PROF(Epi::kName, st);
+    if (k == 15) hipLaunchKernelGGL((k_box_cols<Epi, 15>), grid, blk, 0, st, rs, n, epi, s.B, s.H, s.W, k);
+    else hipLaunchKernelGGL((k_box_cols<Epi, 0>), grid, blk, 0, st, rs, n, epi, s.B, s.H, s.W, k);
 }
 
 // first half of estimate_transmission: six_stadigy.py:170-174 / enhancement_strategies.py:221-225
@@ -425,10 +621,9 @@ int launch_box_filter_f64(const double *d_src, double *d_dst, Shape s, int k, vo
     Carver c(ws);
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n);
-    UWIE_LAUNCH(k_box_rows_lane<SrcPlanes1>, dim3(cdiv(s.H, 64), s.B), dim3(64), 0, st, SrcPlanes1{d_src, s.H, s.W}, rs, n, k);
+    launch_rows_planes(d_src, nullptr, s, rs, n, k, st);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_cols<EpiStore1>, dim3(cdiv((long long)s.B * s.W, 64)), dim3(64), 0, st, rs, n,
-                       EpiStore1{d_dst}, s.B, s.H, s.W, k);
+    launch_cols(rs, n, EpiStore1{d_dst}, s, k, st);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
@@ -447,14 +642,13 @@ static int launch_guided_t(const uint8_t *d_gray, const TP *d_t0, Shape s, int k
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
-    const dim3 grows(cdiv(s.H, kTR), s.B), gcols(cdiv((long long)s.B * s.W, 64)), blk(64);
-    UWIE_LAUNCH(k_box_rows_lane<SrcGuideT<TP>>, grows, blk, 0, st, SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k);
+    launch_rows_lane(SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k, s.B, st);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_cols<EpiAB>, gcols, blk, 0, st, rs, n, EpiAB{pa, pb, eps}, s.B, s.H, s.W, k);
+    launch_cols(rs, n, EpiAB{pa, pb, eps}, s, k, st);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_rows_lane<SrcPlanes2>, grows, blk, 0, st, SrcPlanes2{pa, pb, s.H, s.W}, rs, n, k);
+    launch_rows_planes(pa, pb, s, rs, n, k, st);
     UWIE_LAUNCH_CHECK();
-    UWIE_LAUNCH(k_box_cols<EpiQ>, gcols, blk, 0, st, rs, n, EpiQ{d_gray, d_t}, s.B, s.H, s.W, k);
+    launch_cols(rs, n, EpiQ{d_gray, d_t}, s, k, st);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
