@@ -82,7 +82,7 @@ typedef struct uwie_params {
                               last bit of t decides its byte -- about one pixel in 1e9 bytes (two in a 25 440-case soak,
                               profiles/r03_soak.txt; tests/test_gpu_fuzz.py keeps one such frame) -- and that pixel then
                               differs by up to CLAHE's local slope (<= clip_limit) times gamma's slope: 2 - 3 LSB seen,
-                              1 LSB without CLAHE.  gf_exact = 1 has no such pixel; it costs ~4x the filter's time.
+                              1 LSB without CLAHE.  gf_exact = 1 has no such pixel; it costs ~6x the filter's time.
                               The DICT surface's float64 image differs in its last bits (<= 1e-11) under gf_exact = 0. */
     int32_t inter_dtype;   /* number format of the guided filter's a/b intermediates (S6:39-43) when gf_exact = 0:
                               UWIE_INTER_F64 (default) float64 like the reference; UWIE_INTER_FX32 32-bit fixed

@@ -4,8 +4,8 @@
 //
 // cv2.boxFilter on CV_64F data is a running sum along each border-extended row (s += E[x+k] - E[x]) followed by
 // a running sum down each column (s0 = SUM + Sp; out = s0 * 1/(k*k); SUM = s0 - Sm), so every output's rounding
-// depends on the whole chain from the left / top edge.  This first implementation keeps those chains literally:
-// one thread walks one row (k_box_rows) or one column (k_box_cols) in float64.  Anchor k/2 and
+// depends on the whole chain from the left / top edge.  The kernels of this file keep those chains literally:
+// one lane walks one row (k_box_rows_lane / k_box_rows_ring) or one column (k_box_cols) in float64.  Anchor k/2 and
 // BORDER_REFLECT_101 as in OpenCV; for even k the window is [x - k/2, x + k/2 - 1].
 #include "common.h"
 #include "devutil.h"
@@ -14,7 +14,7 @@ namespace uwie {
 
 namespace {
 
-// ---- sources for the row pass.  Raw = what is staged in LDS per pixel; plane(raw, w) = the value of plane w.
+// ---- sources for the row pass.  Raw = what a lane holds per pixel; plane(raw, w) = the value of plane w.
 typedef double2 __attribute__((aligned(8))) gdouble2_a8;
 typedef float4 __attribute__((aligned(4))) gfloat4_a4;
 typedef uint32_t __attribute__((aligned(1))) gu32_a1;
@@ -115,65 +115,8 @@ struct SrcGuideT {
 };
 using SrcGuide = SrcGuideT<float>;
 
-// Row pass: RowSum<double,double> of cv2.boxFilter.  One workgroup owns 64 rows of one image; wave w owns plane w
-// and lane r owns row r, so every row's running sum is the literal left-to-right chain
-//     s = E[0] + ... + E[k-1];   out[0] = s;   s += E[x+k] - E[x];   out[x+1] = s
-// while all HBM traffic is coalesced: 64x16 tiles of the source are staged through LDS (a "lead" tile at x+k and a
-// "trail" tile at x, both read row-contiguously), and each wave's 64x16 result tile goes back out row-contiguously.
-constexpr int kTR = 64, kTC = 16, kTS = kTC + 1;  // tile rows, tile columns, padded LDS row stride
-
-template <class Src>
-__global__ void __launch_bounds__(64 * Src::NP) k_box_rows(Src src, double *__restrict__ out, size_t plane_stride, int k)
-{
-    constexpr int NP = Src::NP, NT = 64 * NP;
-    using Raw = typename Src::Raw;
-    __shared__ double ilut[256];
-    __shared__ Raw lead[kTR * kTS], trail[kTR * kTS];
-    __shared__ double otile[NP][kTR * kTS];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < 256; i += NT) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
-    const int b = blockIdx.y, y0 = blockIdx.x * kTR, H = src.H, W = src.W, a = k / 2;
-    const int nrows = min(kTR, H - y0);
-    // dst[r][c] = E[j0 + c]: the border-extended row (BORDER_REFLECT_101, anchor a), j in [0, W + k - 1)
-    auto stage = [&](Raw *dst, int j0) {
-        for (int e = tid; e < kTR * kTC; e += NT) {
-            const int r = e / kTC, c = e % kTC, j = j0 + c;
-            if (r < nrows && j >= 0 && j < W + k - 1) dst[r * kTS + c] = src.load(b, y0 + r, reflect101(j - a, W));
-        }
-    };
-    double s = 0.0;
-    for (int j0 = 0; j0 < k; j0 += kTC) {
-        __syncthreads();
-        stage(lead, j0);
-        __syncthreads();
-        if (lane < nrows)
-            for (int c = 0; c < kTC && j0 + c < k; ++c) s += Src::plane(lead[lane * kTS + c], w, ilut);
-    }
-    double *obase = out + (size_t)w * plane_stride + ((size_t)b * H + y0) * W;
-    for (int col0 = 0; col0 < W; col0 += kTC) {
-        __syncthreads();
-        stage(lead, col0 - 1 + k);
-        stage(trail, col0 - 1);
-        __syncthreads();
-        if (lane < nrows) {
-#pragma unroll
-            for (int c = 0; c < kTC; ++c) {
-                const int col = col0 + c;
-                if (col > 0 && col < W)
-                    s += Src::plane(lead[lane * kTS + c], w, ilut) - Src::plane(trail[lane * kTS + c], w, ilut);
-                otile[w][lane * kTS + c] = s;
-            }
-        }
-        __syncthreads();
-        for (int e = lane; e < kTR * kTC; e += 64) {
-            const int r = e / kTC, c = e % kTC;
-            if (r < nrows && col0 + c < W) obase[(size_t)r * W + col0 + c] = otile[w][r * kTS + c];
-        }
-    }
-}
-
 // Row pass, round 4: the same literal chain, one LANE per row and every plane of the row in that lane.
-// k_box_rows above stages 64 x 16 tiles through LDS for a workgroup of NP wavefronts: 240 barrier-separated tiles of a 4K row,
+// Rounds 1-3 staged 64 x 16 tiles through LDS for a workgroup of NP wavefronts: 240 barrier-separated tiles of a 4K row,
 // each a global round trip (4.0 + 2.6 ms of the exact-order filter's 10.0 at 4K x 16).  Here a workgroup is ONE wavefront that
 // owns 64 rows: a lane reads its row's entering and leaving elements CH columns at a time (16-byte loads, the next trip's
 // issued before this trip's arithmetic), keeps the NP running sums in registers (NP independent dependency chains per lane)
