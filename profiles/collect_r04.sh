@@ -6,7 +6,7 @@
 #   gpurun_out/<tag>_4k64_pmc_summary.txt    per-kernel HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) and SQ counters
 #   gpurun_out/<tag>_traffic.json            the table bench.py's roofline.traffic reads (copy to profiles/r04_traffic.json)
 #   gpurun_out/<tag>_uniform_*               the same kernel stats / SQ summary for --dist uniform (dense Canny maps)
-#   gpurun_out/<tag>_1080p_batch1_timeline.txt, <tag>_secondary_4k16.txt, <tag>_guided_sq_summary.txt, <tag>_exact_mode_4k16.txt, <tag>_stream_4k.txt
+#   gpurun_out/<tag>_1080p_batch1_timeline.txt, <tag>_secondary_4k16.txt, <tag>_guided_sq_summary.txt, <tag>_exact_mode_4k64.txt, <tag>_stream_4k.txt
 # The raw counter CSVs (tens of MB per pass) are folded on the box and deleted: gpurun copies back at most 64 MiB.
 TAG=$1
 R=$GRAFT_REPO_ROOT
@@ -46,7 +46,7 @@ python3 profiles/time_strategies.py > $O/${TAG}_secondary_4k16.txt 2>&1
 KFILTER=guided bash profiles/pmc_sq.sh ${TAG}_guided --no-extras > /dev/null 2>&1
 python3 profiles/summarize_sq.py $O/sq_${TAG}_guided guided > $O/${TAG}_guided_sq_summary.txt 2>&1
 rm -rf $O/sq_${TAG}_guided $O/sq_${TAG}_guided.*.log
-python3 profiles/time_exact.py > $O/${TAG}_exact_mode_4k16.txt 2>&1
+python3 profiles/time_exact.py 2160 3840 64 > $O/${TAG}_exact_mode_4k64.txt 2>&1
 for inter in f64 f32t; do
   timeout -k 10 300 python bench.py --mode stream --batch 32 --chunk 8 --steps 3 --warmup 1 --inter $inter 2>/dev/null | tail -1 >> $O/${TAG}_stream_4k.txt
 done

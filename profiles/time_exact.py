@@ -6,6 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import underwater_image_enhancement_amd._lib as _L  # noqa: E402
+
+if os.environ.get("UWIE_AB_LIB"):  # an A/B build (profiles/ab.sh): lib_b or lib_c
+    _L.LIB_PATH = os.path.join(os.path.dirname(_L.__file__), os.environ["UWIE_AB_LIB"], "libuwie.so")
 import underwater_image_enhancement_amd as uw  # noqa: E402
 
 H, W, B = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (2160, 3840, 16)))

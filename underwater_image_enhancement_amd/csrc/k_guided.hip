@@ -18,6 +18,13 @@ namespace {
 typedef double2 __attribute__((aligned(8))) gdouble2_a8;
 typedef float4 __attribute__((aligned(4))) gfloat4_a4;
 typedef uint32_t __attribute__((aligned(1))) gu32_a1;
+typedef double gd2v __attribute__((ext_vector_type(2), aligned(8)));
+// The float64 planes are written once and read once, tens of GB behind: nontemporal stores everywhere and nontemporal loads
+// in the column pass (a lane's loads there are whole 512-byte runs of a row) took the four passes from 16.9 to 16.25 ms at
+// 4K x 64 (A/B inside one run).  The row passes' loads stay plain: their lines are shared between trips.
+__device__ __forceinline__ void st_d2(double *p, double v0, double v1) { __builtin_nontemporal_store(gd2v{v0, v1}, reinterpret_cast<gd2v *>(p)); }
+__device__ __forceinline__ void st_d1(double *p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ double ld_d1(const double *p) { return __builtin_nontemporal_load(p); }
 
 struct SrcPlanes1 {
     const double *p;
@@ -236,7 +243,7 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
             for (int i = 0; i < LPR; ++i) {
                 const int row = i * RPI + t_row;
                 const double v0 = otile[p][row * kLaneOT + t_col], v1 = otile[p][row * kLaneOT + t_col + 1];
-                if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
+                if (y0 + row < H) st_d2(op + (size_t)row * W, v0, v1);
             }
         }
         gwave_lds_sync();
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(64) k_box_rows_ring(const double *__restrict__
     // the coalesced side: instruction i covers rows i * 8 + lane / 8 (clamped into the frame), two columns per lane
     auto load_run = [&](int x, gdouble2_a8 (&r)[LPR]) {
 #pragma unroll
-        for (int i = 0; i < LPR; ++i)
+        for (int i = 0; i < LPR; ++i)  // (plain loads: a row's run shares its lines with the next trip's; nontemporal, 3.7 -> 5.0 ms)
             r[i] = *reinterpret_cast<const gdouble2_a8 *>(src + (size_t)min(y0 + i * RPI + t_row, H - 1) * W + x + t_col);
     };
     auto put_run = [&](int slot, const gdouble2_a8 (&r)[LPR]) {
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(64) k_box_rows_ring(const double *__restrict__
         for (int i = 0; i < LPR; ++i) {
             const int row = i * RPI + t_row;
             const double v0 = otile[row * kLaneOT + t_col], v1 = otile[row * kLaneOT + t_col + 1];
-            if (y0 + row < H) *reinterpret_cast<gdouble2_a8 *>(op + (size_t)row * W) = gdouble2_a8{v0, v1};
+            if (y0 + row < H) st_d2(op + (size_t)row * W, v0, v1);
         }
         gwave_lds_sync();
     }
@@ -358,7 +365,7 @@ struct EpiStore1 {
     double *dst;
     static constexpr const char *kName = "k_box_cols<EpiStore1>";
     static constexpr int NP = 1, U = 7;  // U: rows per load batch of the ring walk in k_box_cols
-    __device__ __forceinline__ void operator()(const double *, size_t i, const double *m) const { dst[i] = m[0]; }
+    __device__ __forceinline__ void operator()(const double *, size_t i, const double *m) const { st_d1(dst + i, m[0]); }
 };
 struct EpiAB {  // a = cov/(var+eps), b = mean_p - a*mean_I (six_stadigy.py:34-40)
     double *a, *b;
@@ -370,8 +377,8 @@ struct EpiAB {  // a = cov/(var+eps), b = mean_p - a*mean_I (six_stadigy.py:34-4
         const double cov = m[2] - m[0] * m[1];
         const double var = m[3] - m[0] * m[0];
         const double av = cov / (var + eps);
-        a[i] = av;
-        b[i] = m[1] - av * m[0];
+        st_d1(a + i, av);
+        st_d1(b + i, m[1] - av * m[0]);
     }
 };
 struct EpiQ {  // q = mean_a*I + mean_b, then np.clip(q, 0.1, 1.0) (six_stadigy.py:45,180)
@@ -382,7 +389,7 @@ struct EpiQ {  // q = mean_a*I + mean_b, then np.clip(q, 0.1, 1.0) (six_stadigy.
     __device__ __forceinline__ void operator()(const double *ilut, size_t i, const double *m) const
     {
         const double q = m[0] * ilut[gray[i]] + m[1];
-        t[i] = fmin(fmax(q, 0.1), 1.0);
+        st_d1(t + i, fmin(fmax(q, 0.1), 1.0));
     }
 };
 
@@ -433,11 +440,11 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
 #pragma unroll
             for (int u = 0; u < R; ++u)  // the rows that leave at steps y .. y + R - 1: y - a + u
 #pragma unroll
-                for (int p = 0; p < NP; ++p) ring[u][p] = base[p * plane_stride + (size_t)(y - a + u) * W];
+                for (int p = 0; p < NP; ++p) ring[u][p] = ld_d1(base + p * plane_stride + (size_t)(y - a + u) * W);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) in[u][p] = base[p * plane_stride + (size_t)(y + K - 1 - a + u) * W];
+                for (int p = 0; p < NP; ++p) in[u][p] = ld_d1(base + p * plane_stride + (size_t)(y + K - 1 - a + u) * W);
             for (; y + R <= y_hi; y += R) {
 #pragma unroll
                 for (int h = 0; h < NB; ++h) {
@@ -446,7 +453,7 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
                     for (int u = 0; u < U; ++u) {  // (past the last period: any valid row, the values are dropped)
                         const size_t r = (size_t)min(y + (h + 1) * U + K - 1 - a + u, H - 1) * W;
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) nx[u][p] = base[p * plane_stride + r];
+                        for (int p = 0; p < NP; ++p) nx[u][p] = ld_d1(base + p * plane_stride + r);
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
