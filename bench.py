@@ -205,7 +205,7 @@ def extras(dev, args, torch, _lib):
             rows = dev.profile_rows()
             dev.profile(False)
             res[f"{tag}_restore_hist_plus_stretch_lab_ms"] = round(
-                sum(v[0] / max(v[1], 1) for n, v in rows.items() if n.startswith(("k_restore_hist_collect", "k_stretch_lab_lut"))), 3)
+                sum(v[0] / max(v[1], 1) for n, v in rows.items() if n.startswith(("k_restore_hist_collect", "k_restore_rank", "k_stretch_lab_lut"))), 3)
     del fr
     # N1: the batch driver's fan-out, all six strategies per frame with shared cast detection / quadtree
     fan = synth_frames("underwater", min(B, 16), H, W, dev.torch_device, seed=1000 * 2)
