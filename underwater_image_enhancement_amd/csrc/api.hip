@@ -66,7 +66,7 @@ const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::
                            {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
                            {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass},
                            {"canny_fault_inject", &Tuning::canny_fault_inject}, {"rank_sweep", &Tuning::rank_sweep},
-                           {"gf_fuse", &Tuning::gf_fuse}};
+                           {"gf_fuse", &Tuning::gf_fuse}, {"exact_fused", &Tuning::exact_fused}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only
 {

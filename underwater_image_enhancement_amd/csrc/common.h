@@ -103,6 +103,7 @@ struct Tuning {
     int gf_fuse = 0;            // ... with t0 computed from the frame's bytes inside it (k_guided_split8: -0.08 ms per 4K x 64 step, opt-in; 0: k_trans_init + t0 plane)
     int rank_sweep = 1;         // strategies 1-2: the rank-counting restore sweep on jobs of >= 16 MP (0: the histogram sweep; 2: any size)
     int canny_fault_inject = 0; // tests only: k_canny_gradnms leaves out the root labels (the round-3 defect): uwie_device_status must report it
+    int exact_fused = 1;         // gf_exact = 1, k = 15: rows and columns of the first box filter in one kernel (0: separate passes)
 };
 const Tuning &tune();  // tuning of the context whose entry point is running on this host thread (defaults outside one)
 uwie_ctx *current_ctx();

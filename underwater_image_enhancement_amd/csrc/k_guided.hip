@@ -9,6 +9,7 @@
 // BORDER_REFLECT_101 as in OpenCV; for even k the window is [x - k/2, x + k/2 - 1].
 #include "common.h"
 #include "devutil.h"
+#include "guided_wave.h"
 
 namespace uwie {
 
@@ -142,14 +143,17 @@ constexpr int kLaneOT = 17;  // tile row stride in doubles: lane = row writes hi
 // K > 0: the window is known at compile time and no leaving element is loaded at all -- E[col - 1] entered the window K
 // columns earlier, so the lane keeps its last ceil(K / CH) runs of entering elements in registers.  K = 0: any window, the
 // leaving run is loaded like the entering one (it hits in L2).
-template <class Src, int K>
+// BOUND: nothing but the running sums in front of every 16th column is stored -- out[((b * nstrips + j) * NP + p) * H + y] =
+// the sum of row y before column 16 j (j = 0: the initial sum, which is column 0's result) -- for k_box_fused_ab below, whose
+// workgroups restart the chains there; plane_stride then carries nstrips.
+template <class Src, int K, bool BOUND = false>
 __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restrict__ out, size_t plane_stride, int k_rt)
 {
     constexpr int NP = Src::NP, CH = Src::CH;  // CH = 8 or 16 columns per trip
     constexpr int D = K > 0 ? (K + CH - 1) / CH : 1;  // runs of history in front of the current one
     using Raw = typename Src::Raw;
     __shared__ double ilut[256];
-    __shared__ double otile[NP][64 * kLaneOT];
+    __shared__ double otile[BOUND ? 1 : NP][BOUND ? 1 : 64 * kLaneOT];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
     __syncthreads();
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         o[p] = out + (size_t)p * plane_stride + ((size_t)b * H + y) * W;
-        if (live) o[p][0] = s[p];
+        if (!BOUND && live) o[p][0] = s[p];
     }
     // columns col0 .. col0 + CH - 1: out[col] = (s += E[col - 1 + k] - E[col - 1]); E[j] = src[reflect101(j - a)], so the
     // entering run starts at source column xe(col0) = col0 - 1 + k - a and the leaving one at col0 - 1 - a.
@@ -186,6 +190,11 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
     constexpr int LPR = CH / 2, RPI = 64 / LPR;
     const int t_row = lane / LPR, t_col = (lane % LPR) * 2;
     for (int col0 = 0; col0 < W; col0 += CH) {
+        if (BOUND && (col0 & 15) == 0 && live) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                out[(((size_t)b * plane_stride + (size_t)(col0 >> 4)) * NP + p) * H + y] = s[p];
+        }
         if (!interior(col0)) {  // a trip that touches the left / right border, or the ragged end of the row: element by element
             for (int c = 0; c < CH && col0 + c < W; ++c) {
                 const int col = col0 + c;
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     s[p] += Src::plane(le, p, ilut) - Src::plane(tr, p, ilut);
-                    if (live) o[p][col] = s[p];
+                    if (!BOUND && live) o[p][col] = s[p];
                 }
             }
             primed = false;
@@ -228,13 +237,14 @@ __global__ void __launch_bounds__(64) k_box_rows_lane(Src src, double *__restric
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 s[p] += Src::plane(le, p, ilut) - Src::plane(tr, p, ilut);
-                otile[p][lane * kLaneOT + c] = s[p];
+                if (!BOUND) otile[p][lane * kLaneOT + c] = s[p];
             }
         }
         if (K > 0) {
 #pragma unroll
             for (int i = 0; i < D * CH; ++i) hist[i] = hist[i + CH];
         }
+        if (BOUND) continue;
         gwave_lds_sync();
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -501,6 +511,195 @@ __global__ void __launch_bounds__(64) k_box_cols(const double *__restrict__ rs, 
     for (; y < H; ++y) one_row(y);
 }
 
+// ---- First box filter of the exact-order mode, rows and columns in one kernel (k = 15): the four row-sum planes never
+// leave the chip.  The column chains are sequential from row 0 and the row chains from column 0, so a workgroup can own all
+// rows of a 16-column STRIP only if something hands it the row chains' values at the strip's left edge: k_box_rows_lane<BOUND>
+// walks the rows once for those (2 B/px written instead of 32).  One wavefront per strip then goes down the frame 16 rows at
+// a time, lane = 4 * i + plane throughout:
+//   stage    16 rows x 32 raw columns (x0 - 8 .. x0 + 23: whole 128-byte runs, four lanes per row) -> {I, p} as doubles in LDS
+//   rows     lane (row i, plane): the 16 chain steps s += E[col + 7] - E[col - 8] from the boundary value, literally as
+//            k_box_rows_lane does them; results into a 32-row LDS ring [row & 31][4 * col + plane]
+//   columns  lane (column i, plane): the literal column chain of k_box_cols over the 16 new rows (output row = row - 7,
+//            entering row from the ring, leaving row 14 rows back in the ring, reflected rows at the top / bottom too)
+//   a, b     lane (output row i, 4 columns): the four means of a pixel from LDS, EpiAB's arithmetic, 32-byte stores
+// Frames of at least 16 rows; the edge strips stage their raw columns element by element (BORDER_REFLECT_101).
+constexpr int kFuseRS = 68;  // ring / means row stride in doubles: 64 + 4 (row-phase writes of 32 lanes hit 32 bank pairs)
+
+template <class TP>
+__global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__ gray, const TP *__restrict__ t0,
+                                                     const double *__restrict__ bound, int H, int W, int nstrips, double eps,
+                                                     double *__restrict__ pa, double *__restrict__ pb)
+{
+    constexpr int K = 15, A = 7;
+    __shared__ double ilut[256];
+    __shared__ double ring[32 * kFuseRS];
+    __shared__ __attribute__((aligned(16))) double2 stage[16 * 34];  // {I, p}; the column pass's means live here too
+    double *means = reinterpret_cast<double *>(stage);
+    static_assert(sizeof(stage) >= 16 * kFuseRS * sizeof(double), "means alias the stage");
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) ilut[i] = (double)i / 255.0;  // six_stadigy.py:177
+    __syncthreads();
+    const int3 bid = xcd_folded_block();  // neighbouring strips (they share their raw lines) run behind the same L2
+    const int strip = bid.x, b = bid.z, x0 = strip * 16;
+    const int li = lane >> 2, pl = lane & 3;
+    const uint8_t *g = gray + (size_t)b * H * W;
+    const TP *t = t0 + (size_t)b * H * W;
+    const double *bnd = bound + (((size_t)b * nstrips + strip) * 4 + pl) * H;
+    const bool edge = x0 - 8 < 0 || x0 + 24 > W;  // uniform
+    const double scale = 1.0 / ((double)K * (double)K);
+
+    // raw data of one 16-row block: lane (row li, quarter pl) holds raw columns x0 - 8 + 8 pl .. + 7 of row r0 + li
+    struct RawRun {
+        double tv[8];
+        uint32_t gv[8];
+        double s0;  // the chain's value in front of the strip, for (row li, plane pl)
+    };
+    auto fetch = [&](int r0, RawRun &R) {
+        const int y = min(r0 + li, H - 1);
+        R.s0 = bnd[y];
+        const int xs = x0 - 8 + 8 * pl;
+        if (!edge) {
+            const uint8_t *gp = g + (size_t)y * W + xs;
+            const gu32_a1 *gw = reinterpret_cast<const gu32_a1 *>(gp);
+            const uint32_t w0 = gw[0], w1 = gw[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                R.gv[i] = (w0 >> (8 * i)) & 255u;
+                R.gv[4 + i] = (w1 >> (8 * i)) & 255u;
+            }
+            const TP *tp = t + (size_t)y * W + xs;
+            if constexpr (sizeof(TP) == 4) {
+                const gfloat4_a4 v0 = *reinterpret_cast<const gfloat4_a4 *>(tp), v1 = *reinterpret_cast<const gfloat4_a4 *>(tp + 4);
+                R.tv[0] = v0.x; R.tv[1] = v0.y; R.tv[2] = v0.z; R.tv[3] = v0.w;
+                R.tv[4] = v1.x; R.tv[5] = v1.y; R.tv[6] = v1.z; R.tv[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const gdouble2_a8 v = *reinterpret_cast<const gdouble2_a8 *>(tp + i);
+                    R.tv[i] = v.x; R.tv[i + 1] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const size_t q = (size_t)y * W + reflect101(xs + i, W);
+                R.gv[i] = g[q];
+                R.tv[i] = (double)t[q];
+            }
+        }
+    };
+    auto put = [&](const RawRun &R) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stage[li * 33 + 8 * pl + i] = make_double2(ilut[R.gv[i]], R.tv[i]);
+    };
+    // plane pl of a staged element {I, p}: I, p, I * p, I * I -- the two factors are read from the element at lane-constant
+    // offsets (selecting them from a 16-byte read took six v_cndmask per value)
+    const int off_a = pl == 1 ? 1 : 0, off_b = pl == 2 ? 1 : 0;
+    const bool has_b = pl >= 2;
+    auto value = [&](const double2 *e) {
+        const double *d = reinterpret_cast<const double *>(e);
+        const double fa = d[off_a], fb = d[off_b];
+        return has_b ? fa * fb : fa;
+    };
+
+    double sum = 0.0;  // the column chain of (column li, plane pl)
+    // column steps for ring rows r_first .. r_last (r_last < H): output row r - 7 each, its mean into means[r - r_first]
+    auto col_steps = [&](int r_first, int r_last) {
+        for (int r = r_first; r <= r_last; ++r) {
+            if (r < A) continue;
+            if (r == A) {  // SUM of the first K - 1 rows of the extended column, top to bottom (k_box_cols)
+                sum = 0.0;
+                for (int j = 0; j < K - 1; ++j) sum += ring[(reflect101(j - A, H) & 31) * kFuseRS + lane];
+            }
+            const int y = r - A;
+            const double e = ring[(r & 31) * kFuseRS + lane], l = ring[(reflect101(y - A, H) & 31) * kFuseRS + lane];
+            const double s0 = sum + e;
+            means[(r - r_first) * kFuseRS + lane] = s0 * scale;
+            sum = s0 - l;
+        }
+    };
+    // a, b of output rows y_first + (0 .. n_rows - 1) from means: lane (row li, columns 4 pl .. 4 pl + 3)
+    auto epilogue = [&](int y_first, int n_rows) {
+        const int y = y_first + li;
+        if (li >= n_rows || y < 0) return;
+        double av[4], bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double2 m01 = *reinterpret_cast<const double2 *>(means + li * kFuseRS + (4 * pl + c) * 4);
+            const double2 m23 = *reinterpret_cast<const double2 *>(means + li * kFuseRS + (4 * pl + c) * 4 + 2);
+            const double cov = m23.x - m01.x * m01.y;   // six_stadigy.py:34-40
+            const double var = m23.y - m01.x * m01.x;
+            av[c] = cov / (var + eps);
+            bv[c] = m01.y - av[c] * m01.x;
+        }
+        const size_t o = ((size_t)b * H + y) * W + x0 + 4 * pl;
+        if (x0 + 4 * pl + 4 <= W) {
+            st_d2(pa + o, av[0], av[1]); st_d2(pa + o + 2, av[2], av[3]);
+            st_d2(pb + o, bv[0], bv[1]); st_d2(pb + o + 2, bv[2], bv[3]);
+        } else {
+            for (int c = 0; c < 4 && x0 + 4 * pl + c < W; ++c) {
+                pa[o + c] = av[c];
+                pb[o + c] = bv[c];
+            }
+        }
+    };
+
+    RawRun cur, nxt;
+    fetch(0, cur);
+    for (int r0 = 0; r0 < H; r0 += 16) {
+        put(cur);
+        const double s_in = cur.s0;
+        gwave_lds_sync();
+        if (r0 + 16 < H) fetch(r0 + 16, nxt);  // the next block's loads run under this block's arithmetic
+        // ---- rows: lane (row li, plane pl)
+        if (r0 + li < H) {
+            double s = s_in;
+            const double2 *srow = stage + li * 33;
+            double *rrow = ring + ((r0 + li) & 31) * kFuseRS + pl;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c > 0 || strip > 0) s += value(srow + c + K) - value(srow + c);  // column 0 of the frame is the initial sum itself
+                rrow[4 * c] = s;
+            }
+        }
+        gwave_lds_sync();
+        // ---- columns: lane (column li, plane pl)
+        const int r_last = min(r0 + 15, H - 1);
+        if (r0 >= 16 && r0 + 15 < H) {  // whole block away from the top: the 32 ring reads first, then the chain
+            double e[16], l[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                e[i] = ring[((r0 + i) & 31) * kFuseRS + lane];
+                l[i] = ring[((r0 + i - 2 * A) & 31) * kFuseRS + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double s0 = sum + e[i];
+                means[i * kFuseRS + lane] = s0 * scale;
+                sum = s0 - l[i];
+            }
+        } else {
+            col_steps(r0, r_last);
+        }
+        gwave_lds_sync();
+        epilogue(r0 - A, r_last - r0 + 1);
+        gwave_lds_sync();
+        cur = nxt;
+    }
+    // ---- the last A output rows: their entering rows are reflections of rows the ring still holds
+    {
+        const int y_first = H - A;
+        for (int y = y_first; y < H; ++y) {
+            const double e = ring[(reflect101(y + K - 1 - A, H) & 31) * kFuseRS + lane], l = ring[(reflect101(y - A, H) & 31) * kFuseRS + lane];
+            const double s0 = sum + e;
+            means[(y - y_first) * kFuseRS + lane] = s0 * scale;
+            sum = s0 - l;
+        }
+        gwave_lds_sync();
+        epilogue(y_first, A);
+    }
+}
+
 template <class Epi>
 static void launch_cols(const double *rs, size_t n, Epi epi, Shape s, int k, hipStream_t st)
 {
@@ -592,10 +791,23 @@ static int launch_guided_t(const uint8_t *d_gray, const TP *d_t0, Shape s, int k
     const size_t n = (size_t)s.B * s.npx();
     double *rs = c.take<double>(n * 6);  // 4 row-sum planes + a + b
     double *pa = rs + 4 * n, *pb = rs + 5 * n;
-    launch_rows_lane(SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k, s.B, st);
-    UWIE_LAUNCH_CHECK();
-    launch_cols(rs, n, EpiAB{pa, pb, eps}, s, k, st);
-    UWIE_LAUNCH_CHECK();
+    if (k == 15 && s.H >= 16 && s.W >= 32 && tune().exact_fused) {
+        // rows and columns of the first filter in one kernel; the row chains' values at the strips' left edges first
+        const int nstrips = cdiv(s.W, 16);
+        {
+            UWIE_PROF("k_box_rows_lane<SrcGuideT, bounds>", st);
+            hipLaunchKernelGGL((k_box_rows_lane<SrcGuideT<TP>, 15, true>), dim3(cdiv(s.H, 64), s.B), dim3(64), 0, st,
+                               SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, (size_t)nstrips, k);
+        }
+        UWIE_LAUNCH_CHECK();
+        UWIE_LAUNCH(k_box_fused_ab<TP>, dim3(nstrips, 1, s.B), dim3(64), 0, st, d_gray, d_t0, rs, s.H, s.W, nstrips, eps, pa, pb);
+        UWIE_LAUNCH_CHECK();
+    } else {
+        launch_rows_lane(SrcGuideT<TP>{d_gray, d_t0, s.H, s.W}, rs, n, k, s.B, st);
+        UWIE_LAUNCH_CHECK();
+        launch_cols(rs, n, EpiAB{pa, pb, eps}, s, k, st);
+        UWIE_LAUNCH_CHECK();
+    }
     launch_rows_planes(pa, pb, s, rs, n, k, st);
     UWIE_LAUNCH_CHECK();
     launch_cols(rs, n, EpiQ{d_gray, d_t}, s, k, st);
