@@ -548,25 +548,21 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
     const bool edge = x0 - 8 < 0 || x0 + 24 > W;  // uniform
     const double scale = 1.0 / ((double)K * (double)K);
 
-    // raw data of one 16-row block: lane (row li, quarter pl) holds raw columns x0 - 8 + 8 pl .. + 7 of row r0 + li
+    // raw data of one 16-row block: lane (row li, quarter pl) holds raw columns x0 - 8 + 8 pl .. + 7 of row r0 + li, exactly as
+    // loaded (a conversion at the load would make the wavefront wait for it at once; the loads run two blocks ahead)
     struct RawRun {
-        double tv[8];
-        uint32_t gv[8];
-        double s0;  // the chain's value in front of the strip, for (row li, plane pl)
+        TP tv[8];
+        uint32_t g0, g1;  // the eight guide bytes
+        double s0;        // the chain's value in front of the strip, for (row li, plane pl)
     };
     auto fetch = [&](int r0, RawRun &R) {
         const int y = min(r0 + li, H - 1);
         R.s0 = bnd[y];
         const int xs = x0 - 8 + 8 * pl;
         if (!edge) {
-            const uint8_t *gp = g + (size_t)y * W + xs;
-            const gu32_a1 *gw = reinterpret_cast<const gu32_a1 *>(gp);
-            const uint32_t w0 = gw[0], w1 = gw[1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                R.gv[i] = (w0 >> (8 * i)) & 255u;
-                R.gv[4 + i] = (w1 >> (8 * i)) & 255u;
-            }
+            const gu32_a1 *gw = reinterpret_cast<const gu32_a1 *>(g + (size_t)y * W + xs);
+            R.g0 = gw[0];
+            R.g1 = gw[1];
             const TP *tp = t + (size_t)y * W + xs;
             if constexpr (sizeof(TP) == 4) {
                 const gfloat4_a4 v0 = *reinterpret_cast<const gfloat4_a4 *>(tp), v1 = *reinterpret_cast<const gfloat4_a4 *>(tp + 4);
@@ -580,17 +576,23 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
                 }
             }
         } else {
+            R.g0 = R.g1 = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const size_t q = (size_t)y * W + reflect101(xs + i, W);
-                R.gv[i] = g[q];
-                R.tv[i] = (double)t[q];
+                const uint32_t gq = g[q];
+                if (i < 4) R.g0 |= gq << (8 * i);
+                else R.g1 |= gq << (8 * (i - 4));
+                R.tv[i] = t[q];
             }
         }
     };
     auto put = [&](const RawRun &R) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) stage[li * 33 + 8 * pl + i] = make_double2(ilut[R.gv[i]], R.tv[i]);
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t gq = ((i < 4 ? R.g0 : R.g1) >> (8 * (i & 3))) & 255u;
+            stage[li * 33 + 8 * pl + i] = make_double2(ilut[gq], (double)R.tv[i]);
+        }
     };
     // plane pl of a staged element {I, p}: I, p, I * p, I * I -- the two factors are read from the element at lane-constant
     // offsets (selecting them from a 16-byte read took six v_cndmask per value)
@@ -644,13 +646,14 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
         }
     };
 
-    RawRun cur, nxt;
+    RawRun cur, nxt, nx2;  // loads run two blocks ahead of their use (a block is shorter than a load under traffic)
     fetch(0, cur);
+    fetch(16, nxt);  // (rows past the end are clamped: H >= 16)
     for (int r0 = 0; r0 < H; r0 += 16) {
         put(cur);
         const double s_in = cur.s0;
         gwave_lds_sync();
-        if (r0 + 16 < H) fetch(r0 + 16, nxt);  // the next block's loads run under this block's arithmetic
+        if (r0 + 32 < H) fetch(r0 + 32, nx2);
         // ---- rows: lane (row li, plane pl)
         if (r0 + li < H) {
             double s = s_in;
@@ -685,6 +688,7 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
         epilogue(r0 - A, r_last - r0 + 1);
         gwave_lds_sync();
         cur = nxt;
+        nxt = nx2;
     }
     // ---- the last A output rows: their entering rows are reflections of rows the ring still holds
     {
