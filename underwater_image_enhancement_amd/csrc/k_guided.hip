@@ -646,14 +646,14 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
         }
     };
 
-    RawRun cur, nxt, nx2;  // loads run two blocks ahead of their use (a block is shorter than a load under traffic)
-    fetch(0, cur);
-    fetch(16, nxt);  // (rows past the end are clamped: H >= 16)
-    for (int r0 = 0; r0 < H; r0 += 16) {
-        put(cur);
-        const double s_in = cur.s0;
+    // One block of 16 rows: `use` holds its raw data, `fill` receives the loads of the block after the next (two blocks ahead:
+    // a block is shorter than a load under traffic).  The three buffers rotate through the unrolled loop below -- as register
+    // copies (cur = nxt) the rotation made the wavefront wait for the youngest loads at every block.
+    auto block = [&](int r0, const RawRun &use, RawRun &fill) {
+        put(use);
+        const double s_in = use.s0;
         gwave_lds_sync();
-        if (r0 + 32 < H) fetch(r0 + 32, nx2);
+        if (r0 + 32 < H) fetch(r0 + 32, fill);
         // ---- rows: lane (row li, plane pl)
         if (r0 + li < H) {
             double s = s_in;
@@ -687,8 +687,14 @@ __global__ void __launch_bounds__(64) k_box_fused_ab(const uint8_t *__restrict__
         gwave_lds_sync();
         epilogue(r0 - A, r_last - r0 + 1);
         gwave_lds_sync();
-        cur = nxt;
-        nxt = nx2;
+    };
+    RawRun b0, b1, b2;
+    fetch(0, b0);
+    fetch(16, b1);  // (rows past the end are clamped: H >= 16)
+    for (int r0 = 0; r0 < H; r0 += 48) {
+        block(r0, b0, b2);
+        if (r0 + 16 < H) block(r0 + 16, b1, b0);
+        if (r0 + 32 < H) block(r0 + 32, b2, b1);
     }
     // ---- the last A output rows: their entering rows are reflections of rows the ring still holds
     {
