@@ -66,7 +66,7 @@ const KnobName kKnobs[] = {{"gf_pipe", &Tuning::gf_pipe}, {"gf_split", &Tuning::
                            {"lin_no_predict", &Tuning::lin_no_predict}, {"q_hist", &Tuning::q_hist}, {"lin_predict_shift", &Tuning::lin_predict_shift},
                            {"streams", &Tuning::streams}, {"canny_prepass", &Tuning::canny_prepass},
                            {"canny_fault_inject", &Tuning::canny_fault_inject}, {"rank_sweep", &Tuning::rank_sweep},
-                           {"gf_fuse", &Tuning::gf_fuse}, {"exact_fused", &Tuning::exact_fused}};
+                           {"gf_fuse", &Tuning::gf_fuse}, {"exact_fused", &Tuning::exact_fused}, {"entry_fuse", &Tuning::entry_fuse}};
 
 void tuning_from_env(Tuning *t)  // uwie_create only
 {
@@ -113,6 +113,9 @@ struct Pipe {
     double *t;
     void *scratch;
     size_t scratch_bytes;
+    uint32_t *qpart;  // level-0 quadrant shares of cast detection's chunks (tuning entry_fuse; inside the scratch, behind what cast
+                      // detection and the quadtree use), or nullptr
+    int32_t *guess;   // ... and the cast kinds its gray plane was first written for
 };
 
 size_t max5(size_t a, size_t b, size_t c, size_t d, size_t e)
@@ -138,6 +141,7 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     P.kind = c.take<int32_t>(s.B);
     P.A = c.take<float>((size_t)s.B * 3);
     P.pct = c.take<float>((size_t)s.B * 3 * kMaxPct);
+    P.guess = c.take<int32_t>(s.B);
     const bool dz = !p || dehazes(p);
     const bool dict_dz = p && p->surface == UWIE_SURFACE_DICT && dz;
     if (dict_dz) {
@@ -167,8 +171,16 @@ Pipe carve_pipe(Carver &c, Shape s, const uwie_params *p)
     const size_t cw = codes_ws_bytes(s, tx > 0 ? tx : 8, ty > 0 ? ty : 8);
     if (cw > P.scratch_bytes) P.scratch_bytes = cw;
     if (dz && !gf_planes && P.scratch_bytes < n * sizeof(float)) P.scratch_bytes = n * sizeof(float);
+    // round 4: cast detection's chunk pass leaves the level-0 quadrant histograms of the quadtree behind (six_stadigy surface with
+    // cast detection on; frames entry_fuse_takes).  They are written before the quadtree starts and read by its first launches.
+    size_t qoff = 0;
+    if (dz && p && p->surface == UWIE_SURFACE_SIX && p->cast_correct && p->forced_cast < 0 && entry_fuse_takes(s, p->min_size)) {
+        qoff = (std::max(cast_ws_bytes(s), airlight_ws_bytes(s)) + 255) & ~size_t(255);
+        if (P.scratch_bytes < qoff + quad_part_bytes(s)) P.scratch_bytes = qoff + quad_part_bytes(s);
+    }
     P.scratch = c.take<char>(P.scratch_bytes);
     if (dz && !gf_planes) P.t0 = static_cast<float *>(P.scratch);
+    if (qoff && P.scratch) P.qpart = reinterpret_cast<uint32_t *>(static_cast<char *>(P.scratch) + qoff);
     return P;
 }
 
@@ -219,15 +231,20 @@ int stage_stretch(const Pipe &P, Shape s, double lo, double hi, float eps, hipSt
 }
 
 // Cast detection (or the forced kind): what every six_stadigy strategy starts from.
+// then_airlight: six_airlight follows on the same Pipe -- the chunk pass may collect the level-0 quadrant histograms for it
+bool quad_from_cast(const uwie_params *p, const Pipe &P) { return P.qpart && p->forced_cast < 0 && p->cast_correct; }
+
 int six_cast(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, const Pipe &P, const int32_t **kind,
-             hipStream_t st)
+             hipStream_t st, bool then_airlight = false)
 {
     *kind = nullptr;
     if (p->forced_cast >= 0) {
         UWIE_TRY(launch_set_kind(P.kind, s.B, p->forced_cast, st));
         *kind = P.kind;
     } else if (p->cast_correct) {
-        UWIE_TRY(launch_cast_classify(ctx, d_in, s, P.kind, nullptr, P.scratch, st));
+        // tuning entry_fuse = 2: histograms only, the gray plane comes out of the quadtree's pre-pass (k_gray_strong)
+        const EntryFuse ef{P.qpart, tune().entry_fuse == 2 ? nullptr : P.gray, P.guess, p->gray_shift};
+        UWIE_TRY(launch_cast_classify(ctx, d_in, s, P.kind, nullptr, P.scratch, st, then_airlight && quad_from_cast(p, P) ? &ef : nullptr));
         *kind = P.kind;
     }
     return UWIE_OK;
@@ -235,9 +252,12 @@ int six_cast(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, 
 
 // Gray plane and atmospheric light: they depend on the (colour-corrected) frame only, so strategies 1-3 share them.
 int six_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Shape s, const uwie_params *p, const Pipe &P,
-                 hipStream_t st)
+                 hipStream_t st, bool after_cast = false)
 {
-    return launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st, p->gray_shift);
+    const bool fused = after_cast && quad_from_cast(p, P);
+    // (gray_shift 0: the plane is there already -- cast detection's chunk pass wrote it)
+    return launch_airlight(ctx, d_in, kind, P.gray, s, p->min_size, P.A, nullptr, P.scratch, st,
+                           fused && tune().entry_fuse != 2 ? 0 : p->gray_shift, fused ? P.qpart : nullptr);
 }
 
 // Strategies 1-3 from (kind, gray, A) on: transmission -> guided filter -> restore -> stretch -> CLAHE / white balance.
@@ -308,9 +328,10 @@ int run_six(uwie_ctx *ctx, const uint8_t *d_in, Shape s, const uwie_params *p, c
             float *d_out_f32, hipStream_t st)
 {
     const int32_t *kind = nullptr;
-    UWIE_TRY(six_cast(ctx, d_in, s, p, P, &kind, st));
-    if (p->strategy >= 1 && p->strategy <= 3) {
-        UWIE_TRY(six_airlight(ctx, d_in, kind, s, p, P, st));
+    const bool dz = p->strategy >= 1 && p->strategy <= 3;
+    UWIE_TRY(six_cast(ctx, d_in, s, p, P, &kind, st, dz));
+    if (dz) {
+        UWIE_TRY(six_airlight(ctx, d_in, kind, s, p, P, st, true));
         return six_dehaze_tail(ctx, d_in, kind, s, p, P, d_out_u8, d_out_f32, st);
     }
     // strategies 4-6 never leave 8-bit data for long: evaluated as per-image LUT chains (k_codes.hip)
@@ -395,6 +416,9 @@ struct FloatPipe {
     double *F64;    // DICT: recovered image, planar
     void *scratch;
     size_t scratch_bytes;
+    uint32_t *qpart;  // level-0 quadrant shares of cast detection's chunks (tuning entry_fuse; inside the scratch, behind what cast
+                      // detection and the quadtree use), or nullptr
+    int32_t *guess;   // ... and the cast kinds its gray plane was first written for
 };
 
 template <class T>
@@ -930,12 +954,12 @@ int uwie_enhance_all_u8(uwie_ctx *ctx, const uint8_t *d_in, uint8_t *d_out_u8, i
     UWIE_CHECK_WS(c.total());
     hipStream_t st = (hipStream_t)stream;
     const int32_t *kind = nullptr;
-    UWIE_TRY(six_cast(ctx, d_in, s, &P6[0], P, &kind, st));
+    UWIE_TRY(six_cast(ctx, d_in, s, &P6[0], P, &kind, st, true));
     if (d_kind) {
         if (kind) UWIE_HIP_CHECK(hipMemcpyAsync(d_kind, kind, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, st));
         else UWIE_HIP_CHECK(hipMemsetAsync(d_kind, 0, sizeof(int32_t) * batch, st));
     }
-    UWIE_TRY(six_airlight(ctx, d_in, kind, s, &P6[0], P, st));
+    UWIE_TRY(six_airlight(ctx, d_in, kind, s, &P6[0], P, st, true));
     const size_t out_stride = (size_t)batch * H * W * 3;
     for (int k = 0; k < 6; ++k) {
         uint8_t *out = d_out_u8 + (size_t)k * out_stride;

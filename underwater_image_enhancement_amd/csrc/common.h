@@ -104,6 +104,8 @@ struct Tuning {
     int rank_sweep = 1;         // strategies 1-2: the rank-counting restore sweep on jobs of >= 16 MP (0: the histogram sweep; 2: any size)
     int canny_fault_inject = 0; // tests only: k_canny_gradnms leaves out the root labels (the round-3 defect): uwie_device_status must report it
     int exact_fused = 1;         // gf_exact = 1, k = 15: rows and columns of the first box filter in one kernel (0: separate passes)
+    int entry_fuse = 1;         // frames with W % 8 == 0: the level-0 quadrant histograms come out of cast detection's chunk pass and the
+                                // gray plane out of the Canny pre-pass (0: k_q_hist<gray> + k_canny_strong as in rounds 3 - 4)
 };
 const Tuning &tune();  // tuning of the context whose entry point is running on this host thread (defaults outside one)
 uwie_ctx *current_ctx();
@@ -166,8 +168,16 @@ struct Shape {
 
 // k_entry.hip
 size_t cast_ws_bytes(Shape s);
+struct EntryFuse {       // what cast detection's chunk pass leaves for the quadtree (tuning entry_fuse)
+    uint32_t *qpart;     // the level-0 quadrants' shares of every chunk
+    uint8_t *gray;       // the gray plane, or nullptr (then the quadtree's level 0 writes it: k_gray_strong)
+    int32_t *guess;      // [B] the cast kinds the plane was first written for
+    int gray_shift;
+};
 int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d_kind, float *d_mean, void *ws,
-                         hipStream_t st);
+                         hipStream_t st, const EntryFuse *ef = nullptr);
+size_t quad_part_bytes(Shape s);  // the level-0 quadrants' shares of every chunk (tuning entry_fuse)
+int launch_quad_hist_reduce(const uint32_t *qpart, Shape s, uint32_t *d_hist, hipStream_t st);
 int launch_set_kind(int32_t *d_kind, int B, int kind, hipStream_t st);
 int launch_normalise_correct(const uint8_t *d_in, const int32_t *d_kind, float *d_out, Shape s, hipStream_t st);
 int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int gray_shift,
@@ -176,14 +186,19 @@ int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gra
 // k_airlight.hip
 size_t airlight_ws_bytes(Shape s);
 // make_gray_shift != 0: d_gray is written on the way (the level-0 sums pass or k_quant_gray) instead of read
+// qpart: the level-0 quadrant shares that launch_cast_classify left for these frames (entry_fuse_takes), or nullptr
 int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int min_size,
-                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift = 0);
+                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift = 0, const uint32_t *qpart = nullptr);
+bool entry_fuse_takes(Shape s, int min_size);
 
 // k_canny.hip  (regions: device array of nreg Region; max_rows/max_cols bound every region)
 size_t canny_ws_bytes(Shape s);
 int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
                  int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed = false,
-                 bool strong_is_zeroed = false);
+                 bool strong_is_zeroed = false, bool prepass_done = false);
+bool gray_strong_takes(Shape s);
+int launch_gray_strong(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, const Region *d_regions, int nreg,
+                       int max_rows, int max_cols, int high, int gray_shift, void *ws, hipStream_t st);
 uint32_t *canny_strong_flags(void *ws, Shape s);  // the pre-pass flags inside a Canny workspace ([regions])
 int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st);
 

@@ -178,6 +178,37 @@ __device__ __forceinline__ uint32_t gray_fixed(uint32_t r, uint32_t g, uint32_t 
                        : (r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14;
 }
 
+// gray_fixed() of four pixels in float32 (round 4: k_gray_strong, k_chunk_hist_quad): R c_r + G c_g + B c_b + 1/2 with
+// c = coefficient / 2^shift is exact (integers below 2^24 scaled by a power of two), so its truncation is gray_fixed();
+// ATT = 1 / 2: the green / blue byte is the attenuated one, 17 u / 20 = trunc(0.85f u + 0.025) (the fractional part of
+// 17 u / 20 is a multiple of 0.05, the float32 error below 3e-5).  d: the twelve bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3.
+static inline void gray_f32_coeffs(int shift, float &cr, float &cg, float &cb)
+{
+    const float sc = shift == 15 ? 1.0f / 32768.0f : 1.0f / 16384.0f;
+    cr = (shift == 15 ? 9798.0f : 4899.0f) * sc;
+    cg = (shift == 15 ? 19235.0f : 9617.0f) * sc;
+    cb = (shift == 15 ? 3735.0f : 1868.0f) * sc;
+}
+template <int ATT>
+__device__ __forceinline__ uint32_t gray1_f32(float r, float g, float b, float cr, float cg, float cb)
+{
+    if (ATT == 1) g = truncf(fmaf(g, 0.85f, 0.025f));
+    if (ATT == 2) b = truncf(fmaf(b, 0.85f, 0.025f));
+    return (uint32_t)fmaf(b, cb, fmaf(g, cg, fmaf(r, cr, 0.5f)));
+}
+template <int ATT>
+__device__ __forceinline__ uint32_t gray4_f32(const uint32_t (&d)[3], float cr, float cg, float cb)
+{
+    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    const uint32_t c0 = d[0], c1 = d[1], c2 = d[2];
+    auto f = [](uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xffu); };
+    const uint32_t g0 = gray1_f32<ATT>(f(c0, 0), f(c0, 1), f(c0, 2), cr, cg, cb);
+    const uint32_t g1 = gray1_f32<ATT>(f(c0, 3), f(c1, 0), f(c1, 1), cr, cg, cb);
+    const uint32_t g2 = gray1_f32<ATT>(f(c1, 2), f(c1, 3), f(c2, 0), cr, cg, cb);
+    const uint32_t g3 = gray1_f32<ATT>(f(c2, 1), f(c2, 2), f(c2, 3), cr, cg, cb);
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+
 // order-preserving integer image of a float32 (radix select, k_select.hip): ascending key == ascending value
 __device__ __forceinline__ uint32_t f32_key(float v)
 {

@@ -1300,8 +1300,16 @@ size_t airlight_ws_bytes(Shape s)
 
 // make_gray_shift != 0: d_gray is not filled yet; the level-0 sums pass writes it (GrayOut) when level 0 is a launched
 // level, k_quant_gray otherwise.  UWIE_Q_GRAY_FUSE=0 always takes k_quant_gray.
+// Level 0 is a launched level with histograms, the frame has whole groups of four pixels on either side of W / 2 and the
+// gray plane is still to be written: cast detection's chunk pass may collect the level-0 histograms (k_chunk_hist_quad).
+bool entry_fuse_takes(Shape s, int min_size)
+{
+    return tune().entry_fuse && tune().q_hist != 0 && gray_strong_takes(s) && s.W <= 16384 && s.H > min_size && s.W > min_size &&
+           (long long)((s.H + 1) / 2) * ((s.W + 1) / 2) > kNpChunk;
+}
+
 int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, int min_size,
-                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift)
+                    float *d_A, void *d_trace, void *ws, hipStream_t st, int make_gray_shift, const uint32_t *qpart)
 {
     Carver c(ws);
     LevelBufs L = carve_level(c, s);
@@ -1344,7 +1352,15 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
             const bool narrow = cdiv(qc, 4) < 256;
             const auto k_q_hist_gray = k_q_hist<true, false>, k_q_hist_gray_narrow = k_q_hist<true, true>;
             const auto k_q_hist_wide = k_q_hist<false, false>, k_q_hist_narrow = k_q_hist<false, true>;
-            if (gray_pending) {
+            // round 4 (tuning entry_fuse): the gray plane comes out of the Canny pre-pass of level 0 (k_gray_strong reads the
+            // frame's bytes once for both), not out of this level's histogram pass
+            const bool gray_by_prepass = gray_pending && level == 0 && tune().entry_fuse && gray_strong_takes(s);
+            bool prepass_done = false;
+            if (level == 0 && qpart) {  // the histograms were counted by cast detection's chunk pass
+                UWIE_REQUIRE(gray_by_prepass || !gray_pending, "airlight: quadrant shares without the fused gray pass");
+                int rc = launch_quad_hist_reduce(qpart, s, L.hist, st);
+                if (rc != UWIE_OK) return rc;
+            } else if (gray_pending && !gray_by_prepass) {
                 if (narrow)
                     UWIE_LAUNCH(k_q_hist_gray_narrow, dim3(nblk, nreg), dim3(256), 0, st, d_in, d_kind, L.regs, s.H, s.W, L.hist, d_gray,
                                 make_gray_shift);
@@ -1360,7 +1376,13 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
                             (uint8_t *)nullptr, 15);
             }
             UWIE_LAUNCH_CHECK();
-            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0);
+            if (gray_by_prepass) {
+                int rc = launch_gray_strong(d_in, d_kind, d_gray, s, L.regs, nreg, qr, qc, 150, make_gray_shift, canny_ws, st);
+                if (rc != UWIE_OK) return rc;
+                gray_pending = false;
+                prepass_done = true;
+            }
+            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0, prepass_done);
             if (rc != UWIE_OK) return rc;
             UWIE_LAUNCH(k_q_decide, dim3(B), dim3(256), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
                         (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip, canny_strong_flags(canny_ws, s),

@@ -173,6 +173,98 @@ __global__ void __launch_bounds__(256) k_canny_strong(const uint8_t *__restrict_
     if (__ballot(hot) && lane == 0) strong[blockIdx.y] = 1;
 }
 
+// ---- level 0 of the quadtree (round 4): gray plane + pre-pass in ONE sweep over the RGB frame -------------------------
+// The four level-0 quadrants are the whole frame, so the pass that answers "any strong pixel?" for them visits every pixel
+// once: it computes the gray bytes itself ((x * 255).astype(u8) -> RGB2GRAY of the colour-corrected value, the integer
+// identities of k_q_hist / tests/test_cabi.py), stores them, and runs the separable Sobel on them -- the frame's bytes are
+// read once here instead of once by the gray-writing histogram pass and the gray plane once more by k_canny_strong.
+// A wavefront owns a strip of 64 four-pixel groups of which the first and the last only supply the horizontal neighbours
+// (248 output columns: strips overlap by two lanes); a lane gets its left / right gray byte from the neighbouring lane's
+// word with one DPP move each.  Requires quadrant widths that are multiples of four (W % 8 == 0).
+// The gray value in float32: R c_r + G c_g + B c_b + 1/2 with c = coefficient / 2^shift is exact (integers below 2^24
+// scaled by a power of two), so its truncation is gray_fixed(); 17 u / 20 of an attenuated byte is trunc(0.85f u + 0.025)
+// (the fractional part of 17 u / 20 is a multiple of 0.05; the float32 error is below 3e-5).
+constexpr int kGsCols = 248;
+
+template <int ATT>
+__device__ void gs_band(const uint8_t *__restrict__ img, uint8_t *__restrict__ gray, int W, const Region &r, int lane, int x,
+                        int y0, int y1, float cr, float cg, float cb, const uint32_t *known, uint32_t &top0, uint32_t &top1)
+{
+    const int xl = min(max(x, 0), r.cols - 4);
+    const bool owner = lane >= 1 && lane <= 62 && x < r.cols;  // (x >= 0 for every lane but lane 0)
+    const bool first = x == 0, last = x + 4 == r.cols;
+    const uint8_t *src = img + ((size_t)r.y0 * W + r.x0 + xl) * 3;
+    uint8_t *dst = gray + (size_t)r.y0 * W + r.x0 + x;
+    struct Raw { uint32_t d[3]; };
+    auto load = [&](int y) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)min(max(y, 0), r.rows - 1) * W * 3);
+        Raw v;
+        v.d[0] = q[0]; v.d[1] = q[1]; v.d[2] = q[2];
+        return v;
+    };
+    const uint32_t no_sh[6] = {};
+    // the row's gray word -> (stored) -> the 6-byte window x-1 .. x+4 -> its separable row terms
+    auto row = [&](const Raw &v, int y, bool keep) {
+        const uint32_t g4 = gray4_f32<ATT>(v.d, cr, cg, cb);
+        if (keep && owner) *reinterpret_cast<uint32_t *>(dst + (size_t)y * W) = g4;
+        uint32_t lf = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g4, 0x138, 0xf, 0xf, false) >> 24;  // wave_shr:1: lane - 1
+        uint32_t rt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g4, 0x130, 0xf, 0xf, false) & 255u;  // wave_shl:1: lane + 1
+        if (first) lf = g4 & 255u;  // BORDER_REPLICATE on the quadrant
+        if (last) rt = g4 >> 24;
+        return pre_row<false>((uint64_t)lf | ((uint64_t)g4 << 8) | ((uint64_t)rt << 40), no_sh);
+    };
+    PreRow a = row(load(y0 - 1), y0 - 1, false), b = row(load(y0), y0, true);
+    v2s m0 = {0, 0}, m1 = {0, 0};
+    for (int yb = y0; yb < y1; yb += 8) {
+        Raw w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = load(min(yb + i, y1 - 1) + 1);  // (past the band: the last row again, harmless)
+        // a region already known to hold a strong pixel only needs its gray bytes (wavefront-uniform)
+        const bool sobel = !__hip_atomic_load(known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (yb + i < y1) {
+                const int yn = yb + i + 1;  // the row below output row yb + i
+                const PreRow c = row(w[i], yn, yn < y1);
+                if (sobel) {
+                    const v2s dx0 = a.hd0 + b.hd0 + b.hd0 + c.hd0, dx1 = a.hd1 + b.hd1 + b.hd1 + c.hd1;
+                    const v2s dy0 = c.hs0 - a.hs0, dy1 = c.hs1 - a.hs1;
+                    m0 = __builtin_elementwise_max(m0, __builtin_elementwise_abs(dx0) + __builtin_elementwise_abs(dy0));
+                    m1 = __builtin_elementwise_max(m1, __builtin_elementwise_abs(dx1) + __builtin_elementwise_abs(dy1));
+                }
+                a = b;
+                b = c;
+            }
+        }
+    }
+    union { v2s v; uint32_t u; } c0, c1;
+    c0.v = m0; c1.v = m1;
+    top0 = owner ? c0.u : 0u;
+    top1 = owner ? c1.u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_gray_strong(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
+                                                     const Region *__restrict__ regs, int H, int W, int strips, int high, float cr,
+                                                     float cg, float cb, uint8_t *__restrict__ gray_out, uint32_t *__restrict__ strong)
+{
+    const Region r = regs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (rows are scalar arithmetic)
+    const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) * 4 + wv;
+    const int x0 = strip * kGsCols - 4, y0 = band * kPreRows;
+    if (x0 + 4 >= r.cols || y0 >= r.rows) return;
+    const int y1 = min(y0 + kPreRows, r.rows), x = x0 + 4 * lane;
+    const uint8_t *img = in + (size_t)r.img * H * W * 3;
+    uint8_t *g = gray_out + (size_t)r.img * H * W;
+    const int knd = kind ? kind[r.img] : 0;
+    uint32_t t0, t1;
+    if (knd == 1) gs_band<1>(img, g, W, r, lane, x, y0, y1, cr, cg, cb, strong + blockIdx.y, t0, t1);
+    else if (knd == 2) gs_band<2>(img, g, W, r, lane, x, y0, y1, cr, cg, cb, strong + blockIdx.y, t0, t1);
+    else gs_band<0>(img, g, W, r, lane, x, y0, y1, cr, cg, cb, strong + blockIdx.y, t0, t1);
+    const int m[4] = {(int)(t0 & 0xffffu), (int)(t0 >> 16), (int)(t1 & 0xffffu), (int)(t1 >> 16)};
+    const bool hot = m[0] > high || m[1] > high || m[2] > high || m[3] > high;
+    if (__ballot(hot) && lane == 0) strong[blockIdx.y] = 1;
+}
+
 // lock-free union-find on tile-local indices in LDS (links point to the smaller index)
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *L, int i)
 {
@@ -761,9 +853,29 @@ uint32_t *canny_strong_flags(void *ws, Shape s)
     return carve_canny(c, s).strong;
 }
 
+// The level-0 quadrants of every frame (regions = the quadtree's first four per image, W % 8 == 0): the gray plane of the
+// colour-corrected frame and the pre-pass flags in one sweep (k_gray_strong); launch_canny then takes prepass_done = true.
+bool gray_strong_takes(Shape s) { return s.W % 8 == 0 && s.W >= 64 && s.H >= 4 && tune().canny_prepass; }
+
+int launch_gray_strong(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, const Region *d_regions, int nreg,
+                       int max_rows, int max_cols, int high, int gray_shift, void *ws, hipStream_t st)
+{
+    Carver c(ws);
+    CannyBufs bufs = carve_canny(c, s);
+    UWIE_REQUIRE(gray_strong_takes(s) && nreg == s.B * 4 && max_cols % 4 == 0, "gray_strong: frame not taken");
+    UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
+    const int strips = cdiv(max_cols, kGsCols), bandgroups = cdiv(cdiv(max_rows, kPreRows), 4);
+    float cr, cg, cb;
+    gray_f32_coeffs(gray_shift, cr, cg, cb);
+    UWIE_LAUNCH(k_gray_strong, dim3(strips * bandgroups, nreg), dim3(256), 0, st, d_in, d_kind, d_regions, s.H, s.W, strips, high,
+                cr, cg, cb, d_gray, bufs.strong);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
 int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows, int max_cols, int low,
                  int high, uint32_t *d_count, uint8_t *d_edges, void *ws, hipStream_t st, bool count_is_zeroed,
-                 bool strong_is_zeroed)
+                 bool strong_is_zeroed, bool prepass_done)
 {
     Carver c(ws);
     CannyBufs bufs = carve_canny(c, s);
@@ -784,7 +896,7 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
     // Pre-pass (edge counts only: the standalone edge map keeps the single pass): regions without a pixel above the high
     // threshold have no edges.  Tuning canny_prepass = 0 disables it.
     if (d_edges || nreg > s.B * 4 || !tune().canny_prepass) bufs.strong = nullptr;
-    if (bufs.strong) {
+    if (bufs.strong && !prepass_done) {  // (prepass_done: launch_gray_strong has filled the flags of these regions)
         if (!strong_is_zeroed) UWIE_HIP_CHECK(hipMemsetAsync(bufs.strong, 0, sizeof(uint32_t) * nreg, st));
         if (max_cols >= 8) {  // the streaming pre-pass loads 8 bytes per row
             const int strips = cdiv(max_cols, kPreCols), bandgroups = cdiv(cdiv(max_rows, kPreRows), 4);

@@ -126,6 +126,243 @@ __global__ void __launch_bounds__(256) k_chunk_hist(const uint8_t *__restrict__ 
     if (tid < kPairs) ties[chunk * kPairs + tid] = (uint8_t)s_tie[tid];
 }
 
+// ---- round 4 (tuning entry_fuse): the level-0 quadrant histograms of the quadtree out of the same pass ----------------
+// compute_Q's score of a level-0 quadrant follows from the quadrant's 3 x 256 byte histogram (k_q_decide), and this pass
+// already counts every byte of the frame: a chunk takes its pixels one quadrant at a time -- the groups of four pixels
+// left of W / 2, then those right of it, of the rows above H / 2, then of the rows below (a chunk is a raster run, so it
+// usually meets two quadrants, the one across the middle row four) -- and folds the lane-column words after each: the
+// fold is the quadrant's share of the chunk (stored as 16-bit pairs in `qpart`, summed per quadrant by
+// k_quad_hist_reduce), the sum of the folds the chunk's histogram as before.  The frame's bytes are read once for cast
+// detection AND the first quadtree level (k_q_hist<gray> read them again: 0.64 ms at 4K x 64).  Requires W % 8 == 0 (whole
+// groups on either side of W / 2).
+// Phase q (0 TL, 1 TR, 2 BL, 3 BR = the order of the quadtree's regions) of the chunk [p0, p1): its groups are numbered
+// row-major over (rows of the half that the chunk touches) x (W / 8 groups of the side); the chunk holds numbers
+// [ga, ga + n).  false: no group.
+__device__ __forceinline__ bool quad_phase(int p0, int p1, int H, int W, int q, int &ra, int &ga, int &n)
+{
+    const int mr = H >> 1, mc = W >> 1, Gh = W >> 3;
+    const int ya = p0 / W, yb = (p1 - 1) / W;
+    const int hf = q >> 1, xs = (q & 1) ? mc : 0;
+    ra = max(ya, hf ? mr : 0);
+    const int rb = min(yb, hf ? H - 1 : mr - 1);
+    ga = 0;
+    n = 0;
+    if (ra > rb) return false;
+    int ge = Gh;
+    if (ra == ya) ga = min(max((p0 - ya * W - xs) >> 2, 0), Gh);
+    if (rb == yb) ge = min(max((p1 - yb * W - xs) >> 2, 0), Gh);
+    n = (rb - ra) * Gh + ge - ga;
+    return n > 0;
+}
+
+// One phase of a chunk (see above): the atomics of its n groups; ATT >= 0 also writes the groups' gray bytes (the gray plane
+// of the colour-corrected frame, six_stadigy.py:149,177, for the cast kind the caller GUESSED: ATT = the attenuated channel,
+// 0 none -- launch_cast_classify repairs the frames whose guess turns out wrong).  gside: the gray plane at the side's column.
+template <int ATT>
+__device__ __forceinline__ void chunk_phase(const uint8_t *__restrict__ side, uint8_t *__restrict__ gside, int W, int Gh, int ra, int ga,
+                                            int n, int tid, char *hb, uint32_t colb, float cr, float cg, float cb)
+{
+    auto bump = [&](uint32_t moved, uint32_t inc) { atomicAdd(reinterpret_cast<uint32_t *>(hb + ((moved & 0x7f80u) | colb)), inc); };
+    constexpr uint32_t kR = 1u, kG = 1u << 10, kB = 1u << 20;
+    constexpr int kAhead = 4, kStep = kAhead * 256, kWords = ATT >= 0 ? 4 : 3;
+    const int dr = 256 / Gh, dg = 256 - dr * Gh;  // a step of 256 groups in (row, group) terms
+    const uint32_t px_safe = (uint32_t)(ra * W + 4 * ga);
+    // cursor of the loads: group tid + ga of the phase's numbering, then 256 further per load
+    int row = ra + (tid + ga) / Gh, gx = (tid + ga) - (row - ra) * Gh;
+    auto fetch = [&](int j0, uint32_t (&d)[kAhead][kWords]) {
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            uint32_t px = (uint32_t)(row * W + 4 * gx);
+            px = j0 + i * 256 < n ? px : px_safe;  // (never under a branch: see k_chunk_hist)
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(side + (size_t)px * 3);
+            d[i][0] = a[0]; d[i][1] = a[1]; d[i][2] = a[2];
+            if constexpr (ATT >= 0) d[i][3] = px;
+            gx += dg;
+            row += dr;
+            if (gx >= Gh) { gx -= Gh; ++row; }
+        }
+    };
+    auto consume = [&](int j0, const uint32_t (&d)[kAhead][kWords]) {
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            if (j0 + i * 256 < n) {
+                const uint32_t c0 = d[i][0], c1 = d[i][1], c2 = d[i][2];
+                bump(c0 << 7, kR); bump(c0 >> 1, kG); bump(c0 >> 9, kB);
+                bump(c0 >> 17, kR); bump(c1 << 7, kG); bump(c1 >> 1, kB);
+                bump(c1 >> 9, kR); bump(c1 >> 17, kG); bump(c2 << 7, kB);
+                bump(c2 >> 1, kR); bump(c2 >> 9, kG); bump(c2 >> 17, kB);
+                if constexpr (ATT >= 0) {
+                    const uint32_t w3[3] = {c0, c1, c2};
+                    *reinterpret_cast<uint32_t *>(gside + d[i][3]) = gray4_f32<ATT>(w3, cr, cg, cb);
+                }
+            }
+        }
+    };
+    uint32_t cur[kAhead][kWords], nxt[kAhead][kWords];
+    fetch(tid, cur);
+    for (int base = tid; base < n; base += 2 * kStep) {
+        fetch(base + kStep, nxt);
+        consume(base, cur);
+        fetch(base + 2 * kStep, cur);
+        consume(base + kStep, nxt);
+    }
+}
+
+// gray_out != nullptr: the gray plane is written on the way for the guessed cast kinds (guess[b])
+__global__ void __launch_bounds__(256) k_chunk_hist_quad(const uint8_t *__restrict__ in, const CastTables *__restrict__ tab,
+                                                         uint32_t *__restrict__ hist2, uint8_t *__restrict__ ties,
+                                                         uint32_t *__restrict__ qpart, int npx, int nchunk, int H, int W,
+                                                         uint8_t *__restrict__ gray_out, const int32_t *__restrict__ guess, float cr,
+                                                         float cg, float cb)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t h[256 * kHistCols];
+    __shared__ uint32_t s_tie[kPairs];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tb = tab->tiebin[tid];
+    for (int i = tid; i < 256 * kHistCols / 4; i += 256) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < kPairs) s_tie[tid] = 0;
+    __syncthreads();
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    uint8_t *gimg = gray_out ? gray_out + (size_t)b * npx : nullptr;
+    const int att = gray_out ? guess[b] : -1;  // (block-uniform)
+    const int p0 = c * kChunkPx, p1 = min(npx, p0 + kChunkPx);
+    const uint32_t colb = (uint32_t)(tid & (kHistCols - 1)) * 4u;
+    char *hb = reinterpret_cast<char *>(h);
+    const int Gh = W >> 3;
+    uint32_t tr = 0, tg = 0, tbl = 0;  // the chunk's counts of byte value `tid`
+    for (int q = 0; q < 4; ++q) {
+        int ra, ga, n;
+        if (!quad_phase(p0, p1, H, W, q, ra, ga, n)) continue;  // (block-uniform; the reducer evaluates the same test)
+        const int xs = (q & 1) ? (W >> 1) : 0;
+        const uint8_t *side = img + (size_t)xs * 3;
+        uint8_t *gside = gimg + xs;
+        if (att < 0) chunk_phase<-1>(side, gside, W, Gh, ra, ga, n, tid, hb, colb, cr, cg, cb);
+        else if (att == 1) chunk_phase<1>(side, gside, W, Gh, ra, ga, n, tid, hb, colb, cr, cg, cb);
+        else if (att == 2) chunk_phase<2>(side, gside, W, Gh, ra, ga, n, tid, hb, colb, cr, cg, cb);
+        else chunk_phase<0>(side, gside, W, Gh, ra, ga, n, tid, hb, colb, cr, cg, cb);
+        __syncthreads();
+        // thread v folds (and clears) the 32 columns of value v: this quadrant's share of the chunk.  Four columns per LDS
+        // instruction, the quads taken in a rotated order (eight neighbouring lanes cover the 32 banks): the fold is a quarter
+        // of the LDS instructions of the b32 version, which made the two folds of a chunk cost as much as a third of its atomics
+        uint32_t r = 0, g = 0, bl = 0;
+#pragma unroll
+        for (int k = 0; k < kHistCols / 4; ++k) {
+            uint4 *wq = reinterpret_cast<uint4 *>(&h[tid * kHistCols + 4 * ((tid + k) & (kHistCols / 4 - 1))]);
+            const uint4 w = *wq;
+            *wq = make_uint4(0, 0, 0, 0);
+            r += (w.x & 1023u) + (w.y & 1023u) + (w.z & 1023u) + (w.w & 1023u);
+            g += ((w.x >> 10) & 1023u) + ((w.y >> 10) & 1023u) + ((w.z >> 10) & 1023u) + ((w.w >> 10) & 1023u);
+            bl += (w.x >> 20) + (w.y >> 20) + (w.z >> 20) + (w.w >> 20);
+        }
+        tr += r; tg += g; tbl += bl;
+        const uint32_t r2 = r | (__shfl_down(r, 1) << 16), g2 = g | (__shfl_down(g, 1) << 16), b2 = bl | (__shfl_down(bl, 1) << 16);
+        if (!(tid & 1)) {
+            uint32_t *out = qpart + (((size_t)b * nchunk + c) * 4 + q) * 384 + (tid >> 1);
+            out[0] = r2; out[128] = g2; out[256] = b2;
+        }
+        __syncthreads();
+    }
+    if (tb < (uint32_t)kCastBinades) {  // same-value stores: no atomics needed
+        if (tr) s_tie[tb] = 1;
+        if (tg) s_tie[kCastBinades + tb] = 1;
+        if (tbl) s_tie[2 * kCastBinades + tb] = 1;
+    }
+    const uint32_t r2 = tr | (__shfl_down(tr, 1) << 16), g2 = tg | (__shfl_down(tg, 1) << 16), b2 = tbl | (__shfl_down(tbl, 1) << 16);
+    const size_t chunk = (size_t)b * nchunk + c;
+    if (!(tid & 1)) {
+        uint32_t *out = hist2 + chunk * 384 + (tid >> 1);
+        out[0] = r2; out[128] = g2; out[256] = b2;
+    }
+    __syncthreads();
+    if (tid < kPairs) ties[chunk * kPairs + tid] = (uint8_t)s_tie[tid];
+}
+
+// The cast kind of a frame guessed from a strided sample of its pixels (exact integer means of the sample, the reference's
+// thresholds on them): only a guess -- k_chunk_hist_quad writes the gray plane for it BEFORE the real decision exists, and
+// the frames whose decision differs get their plane again (k_quant_gray with `unless`).
+constexpr int kGuessPx = 8192, kGuessThreads = 1024, kGuessPer = kGuessPx / kGuessThreads;
+__global__ void __launch_bounds__(kGuessThreads) k_kind_guess(const uint8_t *__restrict__ in, int npx, int32_t *__restrict__ guess)
+{
+    __shared__ uint32_t acc[3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 3) acc[tid] = 0;
+    __syncthreads();
+    const uint8_t *img = in + (size_t)b * npx * 3;
+    const int n = min(npx, kGuessPx);
+    const uint32_t stride = (uint32_t)(npx / n);
+    typedef uint32_t __attribute__((aligned(1))) u32_any;
+    uint32_t w[kGuessPer];
+    // a pixel = the low three bytes of one (unaligned) dword; all of a thread's loads in flight.  The last pixel of the last
+    // frame is read as the dword that ENDS at its last byte.
+#pragma unroll
+    for (int k = 0; k < kGuessPer; ++k) {
+        const int i = min(tid + k * kGuessThreads, n - 1);
+        const size_t px = (size_t)i * stride;
+        const bool tail = px + 1 >= (size_t)npx;
+        const uint32_t v = *reinterpret_cast<const u32_any *>(img + px * 3 - (tail ? 1 : 0));
+        w[k] = tail ? v >> 8 : v;
+    }
+    uint32_t r = 0, g = 0, bl = 0;
+#pragma unroll
+    for (int k = 0; k < kGuessPer; ++k) {
+        if (tid + k * kGuessThreads < n) {
+            r += w[k] & 255u; g += (w[k] >> 8) & 255u; bl += (w[k] >> 16) & 255u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        r += __shfl_xor(r, o); g += __shfl_xor(g, o); bl += __shfl_xor(bl, o);
+    }
+    if ((tid & 63) == 0) { atomicAdd(&acc[0], r); atomicAdd(&acc[1], g); atomicAdd(&acc[2], bl); }
+    __syncthreads();
+    if (tid == 0) {
+        const float sc = 1.0f / (255.0f * (float)n);
+        const float mr = (float)acc[0] * sc, mg = (float)acc[1] * sc, mb = (float)acc[2] * sc;
+        int k = UWIE_CAST_NORMAL;
+        if (mg > mr && mg > mb && (mg - mr) > 0.05f) k = UWIE_CAST_GREENISH;
+        else if (mb > mr && mb > mg && (mb - mr) > 0.05f) k = UWIE_CAST_BLUISH;
+        guess[b] = k;
+    }
+}
+
+// hist[(b * 4 + q) * 768 + channel * 256 + value] += the quadrant's shares of its chunks.  grid (slices, 4, B), 384 threads:
+// thread = one 16-bit pair of qpart; eight loads in flight.
+__global__ void __launch_bounds__(384) k_quad_hist_reduce(const uint32_t *__restrict__ qpart, uint32_t *__restrict__ hist, int npx,
+                                                          int nchunk, int H, int W)
+{
+    const int sl = blockIdx.x, q = blockIdx.y, b = blockIdx.z, kp = threadIdx.x;
+    const int mr = H >> 1;
+    const int pa = (q >> 1) ? mr * W : 0, pb = (q >> 1) ? npx : mr * W;  // the half's pixels
+    if (pb <= pa) return;
+    const int ca = pa / kChunkPx, cb = (pb - 1) / kChunkPx;  // its chunks (inclusive)
+    const int per = (cb - ca + (int)gridDim.x) / (int)gridDim.x;
+    const int c0 = ca + sl * per, c1 = min(cb + 1, c0 + per);
+    if (c0 >= c1) return;
+    const uint32_t *src = qpart + ((size_t)b * nchunk * 4 + q) * 384 + kp;
+    uint32_t lo = 0, hi = 0;
+    for (int c = c0; c < c1; c += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = src[(size_t)min(c + i, c1 - 1) * 4 * 384];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int ra, ga, n;
+            const int cc = c + i;
+            // A phase the chunk kernel skipped was never written.  Only the first and the last chunk of a half can miss a side
+            // (every other chunk lies inside the half and is at least as long as a row: W <= kChunkPx).
+            bool on = cc < c1;
+            if (on && (cc == ca || cc == cb)) on = quad_phase(cc * kChunkPx, min(npx, (cc + 1) * kChunkPx), H, W, q, ra, ga, n);
+            if (on) {
+                lo += w[i] & 0xffffu;
+                hi += w[i] >> 16;
+            }
+        }
+    }
+    uint32_t *out = hist + ((size_t)(b * 4 + q) * 3 + (kp >> 7)) * 256 + 2 * (kp & 127);
+    if (lo) atomicAdd(out, lo);
+    if (hi) atomicAdd(out + 1, hi);
+}
+
 // D for kUlpChunks chunks x 3 channels (48 rows) per block.  D = sum_k n_k R_k with n_k <= 16384 summing to at most 16384
 // and R_k < 2^26: R = hi * 2^13 + lo, both sums stay below 2^27, and v_dot2_u32_u16 takes two values per instruction from
 // the pair tables (CastTables::RT2) -- one instruction per (row, value, binade) where the 64-bit mad + tie count of rounds
@@ -464,8 +701,26 @@ size_t cast_ws_bytes(Shape s)
     return c.total();
 }
 
+__global__ void k_quant_gray(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind, uint8_t *__restrict__ gray, int npx,
+                             int shift, const int32_t *__restrict__ unless);
+
+size_t quad_part_bytes(Shape s) { return (size_t)s.B * cdiv((long long)s.npx(), kChunkPx) * 4 * 384 * sizeof(uint32_t); }
+
+int launch_quad_hist_reduce(const uint32_t *qpart, Shape s, uint32_t *d_hist, hipStream_t st)
+{
+    const int nchunk = cdiv((long long)s.npx(), kChunkPx);
+    const int half_chunks = cdiv(nchunk, 2) + 1;
+    const int slices = std::max(1, std::min(8, half_chunks / 16));
+    UWIE_LAUNCH(k_quad_hist_reduce, dim3(slices, 4, s.B), dim3(384), 0, st, qpart, d_hist, (int)s.npx(), nchunk, s.H, s.W);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+// ef != nullptr (round 4; the caller checked entry_fuse_takes): the chunk pass also leaves the level-0 quadrants' shares of
+// every chunk in ef->qpart ([B][chunks][4][384] 16-bit pairs) for launch_quad_hist_reduce and, with ef->gray, writes the
+// gray plane of the colour-corrected frame -- for a guessed cast kind first, again for the frames whose guess was wrong.
 int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d_kind, float *d_mean, void *ws,
-                         hipStream_t st)
+                         hipStream_t st, const EntryFuse *ef)
 {
     Carver c(ws);
     const int npx = (int)s.npx();
@@ -474,7 +729,20 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     uint8_t *ties = c.take<uint8_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     uint64_t *ulps = c.take<uint64_t>((size_t)s.B * nchunk * 3 * kCastBinades);
     float *sums = c.take<float>((size_t)s.B * 3);
-    UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, ctx->d_cast, hist2, ties, npx, nchunk);
+    const bool spec_gray = ef && ef->gray && ef->guess && d_kind;
+    if (ef) {
+        UWIE_REQUIRE(ef->qpart && s.W % 8 == 0 && s.W >= 64 && s.W <= kChunkPx && s.H >= 2, "cast_classify: quadrant shares need W % 8 == 0");
+        float cr = 0, cg = 0, cb = 0;
+        if (spec_gray) {
+            gray_f32_coeffs(ef->gray_shift, cr, cg, cb);
+            UWIE_LAUNCH(k_kind_guess, dim3(s.B), dim3(kGuessThreads), 0, st, d_in, npx, ef->guess);
+            UWIE_LAUNCH_CHECK();
+        }
+        UWIE_LAUNCH(k_chunk_hist_quad, dim3(nchunk, s.B), dim3(256), 0, st, d_in, ctx->d_cast, hist2, ties, ef->qpart, npx, nchunk, s.H,
+                    s.W, spec_gray ? ef->gray : (uint8_t *)nullptr, (const int32_t *)ef->guess, cr, cg, cb);
+    } else {
+        UWIE_LAUNCH(k_chunk_hist, dim3(nchunk, s.B), dim3(256), 0, st, d_in, ctx->d_cast, hist2, ties, npx, nchunk);
+    }
     UWIE_LAUNCH_CHECK();
     // the accumulator never exceeds the pixel count: binades above floor(log2(npx)) are never asked for
     const int nb = std::min(kCastBinades, (31 - __builtin_clz((unsigned)std::max(npx, 1))) - kCastBinadeMin + 1);
@@ -491,6 +759,12 @@ int launch_cast_classify(uwie_ctx *ctx, const uint8_t *d_in, Shape s, int32_t *d
     UWIE_LAUNCH_CHECK();
     UWIE_LAUNCH(k_cast_decide, dim3(cdiv(s.B, 64)), dim3(64), 0, st, sums, s.B, npx, d_kind, d_mean);
     UWIE_LAUNCH_CHECK();
+    if (spec_gray) {  // frames whose guess was wrong (none, as a rule: every block returns at once)
+        const int blocks = std::min(grid_for((s.npx() + 3) / 4, 4096), 256);
+        UWIE_LAUNCH(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, (const int32_t *)d_kind, ef->gray, npx, ef->gray_shift,
+                    (const int32_t *)ef->guess);
+        UWIE_LAUNCH_CHECK();
+    }
     return UWIE_OK;
 }
 
@@ -526,13 +800,16 @@ int launch_normalise_correct(const uint8_t *d_in, const int32_t *d_kind, float *
 }
 
 // gray = cvtColor((x*255).astype(u8), RGB2GRAY) of the (cast-corrected) frame: six_stadigy.py:149,177.
+// unless != nullptr: frames with unless[b] == kind[b] are skipped (their plane was written for that kind already)
 __global__ void __launch_bounds__(256) k_quant_gray(const uint8_t *__restrict__ in, const int32_t *__restrict__ kind,
-                                                    uint8_t *__restrict__ gray, int npx, int shift)
+                                                    uint8_t *__restrict__ gray, int npx, int shift,
+                                                    const int32_t *__restrict__ unless)
 {
     // (x * 255).astype(u8) of the (colour-corrected) value is a map of the byte: one weighted table per channel in LDS
     __shared__ uint32_t wq[3][256];
     const int b = blockIdx.y;
     const int k = kind ? kind[b] : 0;
+    if (unless && unless[b] == k) return;
     const uint8_t *img = in + (size_t)b * npx * 3;
     uint8_t *g = gray + (size_t)b * npx;
     const bool aligned = (npx & 3) == 0;
@@ -562,7 +839,8 @@ int launch_quant_gray(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gra
                       hipStream_t st)
 {
     const int blocks = grid_for((s.npx() + 3) / 4, 4096);
-    UWIE_LAUNCH(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_gray, (int)s.npx(), gray_shift);
+    UWIE_LAUNCH(k_quant_gray, dim3(blocks, s.B), dim3(256), 0, st, d_in, d_kind, d_gray, (int)s.npx(), gray_shift,
+                (const int32_t *)nullptr);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }

@@ -89,7 +89,7 @@ class Device:
     # ------------------------------------------------------------------ route selectors (uwie_set_tuning)
     def tune(self, **selectors):
         """Set route selectors of this context (include/uwie.h: gf_pipe, gf_split, gf_bands, select_generic, restore_store,
-        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, q_hist, streams, canny_prepass).  The selection / storage / quadtree
+        lin_predict3, lin_cap, lin_no_predict, lin_predict_shift, q_hist, streams, canny_prepass, entry_fuse ...).  The selection / storage / quadtree
         selectors give the same bytes on every route, the gf_* ones the same transmission to 1e-11 (uwie.h); tests force the
         fallback routes with it."""
         for name, value in selectors.items():
@@ -287,7 +287,9 @@ class Device:
         check(self.lib.uwie_normalise_correct(self._ctx, _ptr(frames), _ptr(kind), _ptr(out), B, H, W, self.stream()))
         return out
 
-    def atmospheric_light(self, frames, kind=None, p: UwieParams | None = None, trace: bool = False):
+    def atmospheric_light(self, frames, kind=None, p: UwieParams | None = None, trace: bool = False, want_gray: bool = False):
+        """``want_gray``: also return the gray plane the call wrote on its way (uwie_atmospheric_light keeps it in the first
+        B*H*W bytes of its workspace) -- tests compare it with ``transmission_init``'s."""
         B, H, W = self._bhw(frames)
         p = p or self.params(_lib.SURFACE_SIX, 2)
         ws = self.workspace_for(B, H, W, p)
@@ -295,9 +297,11 @@ class Device:
         tr = torch.zeros((B, 32, _TRACE_DTYPE.itemsize), dtype=torch.uint8, device=self.torch_device) if trace else None
         check(self.lib.uwie_atmospheric_light(self._ctx, _ptr(frames), _ptr(kind), B, H, W, ctypes.byref(p), _ptr(A),
                                               _ptr(tr), _ptr(ws), ws.numel(), self.stream()))
-        if trace:
-            return A, tr.cpu().numpy().view(_TRACE_DTYPE).reshape(B, 32)
-        return A
+        out = (A, tr.cpu().numpy().view(_TRACE_DTYPE).reshape(B, 32)) if trace else A
+        if want_gray:
+            gray = ws[: B * H * W].view(B, H, W).clone()
+            return (*out, gray) if trace else (out, gray)
+        return out
 
     def transmission_init(self, frames, A, kind=None, p: UwieParams | None = None):
         B, H, W = self._bhw(frames)
