@@ -118,7 +118,7 @@ def test_near_tie_quadrants_take_the_exact_kernels_after_the_fused_pass(uw):
 
 
 def test_a_wrong_guess_of_the_cast_kind_is_repaired(uw):
-    """The chunk pass writes the gray plane for a cast kind guessed from 8192 strided pixels before the real decision exists.
+    """The chunk pass writes the gray plane for a cast kind guessed from 2048 strided pixels before the real decision exists.
     Frames built so that the guess is wrong both ways (the sampled pixels green on a neutral frame; neutral on a green one):
     k_quant_gray writes their planes again, the output equals the separate passes and the oracle."""
     from oracle import uwie_oracle as orc
@@ -129,13 +129,13 @@ def test_a_wrong_guess_of_the_cast_kind_is_repaired(uw):
     rng = np.random.default_rng(9)
     H, W = 264, 512
     npx = H * W
-    stride = npx // 8192
-    idx = np.arange(8192) * stride
+    stride = npx // 2048
+    idx = np.arange(2048) * stride
     neutral = np.floor(255 * (0.45 + 0.1 * rng.random((H, W, 3)))).astype(np.uint8)
     green = neutral.copy()
     green[:, :, 1] = np.minimum(255, green[:, :, 1].astype(int) + 60)
     a = neutral.copy().reshape(-1, 3)
-    a[idx] = (100, 170, 100)  # guess: greenish; decision: normal (6 % of the pixels move the mean by 0.016)
+    a[idx] = (100, 170, 100)  # guess: greenish; decision: normal (1.5 % of the pixels move the mean by 0.004)
     b = green.copy().reshape(-1, 3)
     b[idx] = (128, 128, 128)  # guess: normal; decision: greenish
     u8 = np.stack([a.reshape(H, W, 3), b.reshape(H, W, 3), neutral, green])

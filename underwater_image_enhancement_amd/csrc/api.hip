@@ -304,7 +304,7 @@ int six_dehaze_tail(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *kind, Sha
         // (small jobs keep the histogram sweep: at 1080p x 1 the rank-counting kernels' fixed costs -- wavefront-private queues,
         // a window-wide list for the finish -- make them 54 + 20 us against 34 + 14; tuning rank_sweep = 2 forces them anyway)
         const bool big = (size_t)s.B * s.npx() >= ((size_t)1 << 24) || tune().rank_sweep >= 2;
-        if (recompute && plan.predicted && !t_is_f32 && tune().rank_sweep && big) {
+        if (recompute && plan.predicted && !t_is_f32 && tune().rank_sweep && big && s.npx() >= 4) {
             // round 4: no histogram at all -- counts below the predicted windows + the windows' members (k_restore_rank)
             UWIE_TRY(launch_restore_rank(src, s, plan, st));
             UWIE_TRY(select_rank_run(plan, P.F, s, st, src));

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_canny_strong(const uint8_t *__restrict_
                                                       int W, int strips, int high, uint32_t *__restrict__ strong)
 {
     const Region r = regs[blockIdx.y];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (rows are scalar arithmetic)
     const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) * 4 + wv;
     const int x0 = strip * kPreCols, y0 = band * kPreRows;
     if (x0 >= r.cols || y0 >= r.rows) return;

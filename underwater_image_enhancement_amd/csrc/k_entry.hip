@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(256) k_chunk_hist_quad(const uint8_t *__restri
 // The cast kind of a frame guessed from a strided sample of its pixels (exact integer means of the sample, the reference's
 // thresholds on them): only a guess -- k_chunk_hist_quad writes the gray plane for it BEFORE the real decision exists, and
 // the frames whose decision differs get their plane again (k_quant_gray with `unless`).
-constexpr int kGuessPx = 8192, kGuessThreads = 1024, kGuessPer = kGuessPx / kGuessThreads;
+// (2048 pixels: one CU gathers them in ~8 us -- 8192 scattered lines took it 23; a wrong guess only costs the repair)
+constexpr int kGuessPx = 2048, kGuessThreads = 256, kGuessPer = kGuessPx / kGuessThreads;
 __global__ void __launch_bounds__(kGuessThreads) k_kind_guess(const uint8_t *__restrict__ in, int npx, int32_t *__restrict__ guess)
 {
     __shared__ uint32_t acc[3];
@@ -710,7 +711,7 @@ int launch_quad_hist_reduce(const uint32_t *qpart, Shape s, uint32_t *d_hist, hi
 {
     const int nchunk = cdiv((long long)s.npx(), kChunkPx);
     const int half_chunks = cdiv(nchunk, 2) + 1;
-    const int slices = std::max(1, std::min(8, half_chunks / 16));
+    const int slices = std::max(1, std::min(32, half_chunks / 8));  // one trip of eight loads per thread where the job has the chunks
     UWIE_LAUNCH(k_quad_hist_reduce, dim3(slices, 4, s.B), dim3(384), 0, st, qpart, d_hist, (int)s.npx(), nchunk, s.H, s.W);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;

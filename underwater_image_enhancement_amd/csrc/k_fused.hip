@@ -480,13 +480,18 @@ __global__ void __launch_bounds__(256) k_restore_rank(RestoreSrc S, int npx, Lin
                          tb_ = *reinterpret_cast<const double2_a8 *>(tpl + (p_) + 2);                                   \
         (tv_)[0] = ta_.x; (tv_)[1] = ta_.y; (tv_)[2] = tb_.x; (tv_)[3] = tb_.y;                                         \
     } while (0)
+    // The next trip's group is loaded UNCONDITIONALLY from a clamped position (the frame's last whole group when there is no
+    // next group): written as `if (have) load`, the loads sat in a block of their own whose join copies their registers -- the
+    // ISA showed s_waitcnt vmcnt right behind them, i.e. every trip waited for the "prefetch" it had just issued (k_chunk_hist
+    // had the same defect in round 3).
     uint32_t w_nx[3] = {0, 0, 0};
     double tv_nx[4] = {1.0, 1.0, 1.0, 1.0};
     bool have_nx = false;
+    const int p_last = npx - 4;  // (launch_restore_rank requires npx >= 4)
     {
         const int p0 = (blockIdx.x * 256 + tid) * 4;
         have_nx = p0 + 4 <= npx;
-        if (have_nx) UWIE_RANK_LOAD4(p0, w_nx, tv_nx);
+        UWIE_RANK_LOAD4(min(p0, p_last), w_nx, tv_nx);
     }
     for (int it = 0; it < iters; ++it) {
         const int p = it * step + (blockIdx.x * 256 + tid) * 4;
@@ -496,7 +501,7 @@ __global__ void __launch_bounds__(256) k_restore_rank(RestoreSrc S, int npx, Lin
         {
             const int pn = p + step;
             have_nx = it + 1 < iters && pn + 4 <= npx;
-            if (have_nx) UWIE_RANK_LOAD4(pn, w_nx, tv_nx);
+            UWIE_RANK_LOAD4(min(pn, p_last), w_nx, tv_nx);
         }
         uint32_t fm = 0;  // bit 4 c + i: value i of channel c lies in a widened window
         seen += 4u * (uint32_t)__popcll(__ballot(have));
@@ -1413,7 +1418,7 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 
 int launch_restore_rank(const RestoreSrc &src, Shape s, const SelectPlan &plan, hipStream_t st)
 {
-    UWIE_REQUIRE(!src.t32 && plan.nq <= 2 && plan.predicted, "restore_rank: float64 transmission, two predicted percentiles");
+    UWIE_REQUIRE(!src.t32 && plan.nq <= 2 && plan.predicted && s.npx() >= 4, "restore_rank: float64 transmission, two predicted percentiles");
     // 25.5 KB of LDS per block.  Blocks per frame as for the histogram sweep (several full rounds of the chip).
     int nblk = cdiv(12288, s.B);
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;

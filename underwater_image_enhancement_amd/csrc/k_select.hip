@@ -856,15 +856,16 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
         sub_scale = 2048.0f * 2048.0f / (float)(s->wspan[g] + 1u);
         for (int i = tid; i < 2048; i += 1024) h[i] = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < cnt; base += 8192) {
-            V x[8];
+        constexpr int kFly = sizeof(V) == 4 ? 16 : 8;  // loads in flight per thread (a lone block: latency is all there is)
+        for (uint32_t base = 0; base < cnt; base += kFly * 1024) {
+            V x[kFly];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t i = base + u * 1024 + tid;
-                x[u] = i < cnt ? L[i] : (V)0;
+            for (int u = 0; u < kFly; ++u) {
+                const uint32_t i = min(base + u * 1024 + tid, cnt - 1);  // (clamped, not predicated: no wait per load)
+                x[u] = L[i];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < kFly; ++u)
                 if (base + u * 1024 + tid < cnt) atomicAdd(&h[subbin(x[u])], 1u);
         }
         __syncthreads();
@@ -886,15 +887,17 @@ __global__ void __launch_bounds__(1024) k_lin_finish(const LinState *__restrict_
     __syncthreads();
     {
         unsigned long long kmin = ~0ull, kmax = 0ull;
-        for (uint32_t base = 0; base < cnt; base += 8192) {  // eight loads in flight per thread
-            V x[8];
+        constexpr int kFly = sizeof(V) == 4 ? 16 : 8;
+        for (uint32_t base = 0; base < cnt; base += kFly * 1024) {  // kFly loads in flight per thread
+            V x[kFly];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kFly; ++u) {
                 const uint32_t i = base + u * 1024 + tid;
-                x[u] = i < cnt ? L[i] : (V)-1;  // (bin 0, never a list's target)
+                const V v = L[min(i, cnt - 1)];  // (clamped load, then the select: no wait per load)
+                x[u] = i < cnt ? v : (V)-1;  // (bin 0, never a list's target)
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kFly; ++u) {
                 const bool mine = is_mine(x[u], base + u * 1024 + tid);
                 const uint64_t m = __ballot(mine);
                 if (m) {  // wavefront-aggregated append
