@@ -152,7 +152,12 @@ int uwie_params_init(uwie_params *p, int surface, int strategy);
  *     the score intervals allow; 0: NumPy-order kernels only; 2: histograms taken, never used; 3: both, and every reference-order
  *     score is checked against its interval -- UWIE_STATUS_QTREE_BOUNDS), canny_prepass (1),
  *     streams (1; 2 .. 4 = sub-batches on internal streams), gf_fuse (1: the transmission's first half is evaluated inside the
- *     guided filter for window 15, same float32 operations; 0: k_trans_init writes a t0 plane first);
+ *     guided filter for window 15, same float32 operations; 0: k_trans_init writes a t0 plane first),
+ *     entry_fuse (1, round 4; SIX surface with cast detection, strategies 1-3, frames whose width is a multiple of 8: the
+ *     level-0 quadrant histograms of estimate_atmospheric_light (S6:49-157) are counted by detect_image_type's own pass over
+ *     the frame (S6:292) and that pass writes the gray plane (S6:149,177) for a cast kind guessed from 2048 pixels -- frames
+ *     whose decision differs get their plane again; 2: histograms from that pass, the gray plane from the quadtree's level-0
+ *     Canny pre-pass; 0: one pass over the frame per stage, as in rounds 1-3);
  *   SAME TRANSMISSION TO 1e-11, hence the u8 contract of uwie_params.gf_exact = 0 -- which fused guided-filter kernel runs:
  *     gf_pipe (1), gf_split (1), gf_bands (0 = chosen from the job).  They sum the same windows in different orders.
  *     (UWIE_INTER_F32T needs the wavefront kernels: with gf_pipe = 0 it keeps float64.)
