@@ -32,7 +32,7 @@ PIPELINE_BYTES_PER_PX = 19.0  # five dependent streaming
 # Quadtree kernels run once per level on a block a quarter the size of the previous one: sum = 4/3.
 Q = 4.0 / 3.0
 KERNEL_BYTES_PER_PX = {
-    "k_chunk_hist": 3, "k_chunk_ulps": 0, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
+    "k_chunk_hist": 3, "k_chunk_hist_quad": 3 + 1, "k_quad_hist_reduce": 0, "k_kind_guess": 0, "k_gray_strong": 3 + 1, "k_chunk_ulps": 0, "k_cast_resolve": 0, "k_cast_decide": 0, "k_quant_gray": 3 + 1,
     "k_q_hist_gray": 3 + 1, "k_q_hist_gray_narrow": 3 + 1, "k_q_hist_wide": 3 * (Q - 1), "k_q_hist_narrow": 3 * (Q - 1), "k_q_decide": 0,
     "k_q_chunk_sums<false>": 3 * Q, "k_q_chunk_sums<true>": 3 * Q, "k_canny_gradnms<true>": 1 * Q, "k_canny_gradnms_weak": (1 + 1) * Q,
     "k_canny_union<true>": 1 * Q, "k_canny_mark<true>": 1 * Q, "k_canny_emit<true>": 1 * Q,
