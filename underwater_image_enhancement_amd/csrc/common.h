@@ -199,6 +199,8 @@ int launch_canny(const uint8_t *d_gray, Shape s, const Region *d_regions, int nr
 bool gray_strong_takes(Shape s);
 int launch_gray_strong(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gray, Shape s, const Region *d_regions, int nreg,
                        int max_rows, int max_cols, int high, int gray_shift, void *ws, hipStream_t st);
+int launch_hist_strong(const uint8_t *d_in, const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows,
+                       int max_cols, int high, uint32_t *d_hist, void *ws, hipStream_t st);
 uint32_t *canny_strong_flags(void *ws, Shape s);  // the pre-pass flags inside a Canny workspace ([regions])
 int launch_make_full_regions(Region *d_regions, Shape s, hipStream_t st);
 

@@ -1356,7 +1356,15 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
             // frame's bytes once for both), not out of this level's histogram pass
             const bool gray_by_prepass = gray_pending && level == 0 && tune().entry_fuse && gray_strong_takes(s);
             bool prepass_done = false;
-            if (level == 0 && qpart) {  // the histograms were counted by cast detection's chunk pass
+            // round 4, levels >= 1 (tuning entry_fuse): histograms and the Canny pre-pass of the level in one sweep (k_hist_strong);
+            // every block of the level is W >> level columns wide when that divides evenly
+            const bool hist_by_prepass = level > 0 && !gray_pending && tune().entry_fuse && tune().canny_prepass &&
+                                         (s.W >> level) << level == s.W && (s.W >> level) % 8 == 0 && qc >= 8;
+            if (hist_by_prepass) {
+                int rc = launch_hist_strong(d_in, d_gray, s, L.regs, nreg, qr, qc, 150, L.hist, canny_ws, st);
+                if (rc != UWIE_OK) return rc;
+                prepass_done = true;
+            } else if (level == 0 && qpart) {  // the histograms were counted by cast detection's chunk pass
                 UWIE_REQUIRE(gray_by_prepass || !gray_pending, "airlight: quadrant shares without the fused gray pass");
                 int rc = launch_quad_hist_reduce(qpart, s, L.hist, st);
                 if (rc != UWIE_OK) return rc;

@@ -265,6 +265,134 @@ __global__ void __launch_bounds__(256) k_gray_strong(const uint8_t *__restrict__
     if (__ballot(hot) && lane == 0) strong[blockIdx.y] = 1;
 }
 
+// ---- levels >= 1 of the quadtree (round 4): the quadrants' byte histograms AND the pre-pass in one sweep ---------------
+// k_q_hist (k_airlight.hip) and k_canny_strong stream over the same four quadrants of the chosen block, one after the
+// other: the first is bound by its LDS atomics, the second by its packed arithmetic.  Here one wavefront does both for its
+// strip and band -- per row three dwords of RGB for the histogram (the lane-column words of k_chunk_hist: the bank of an
+// atomic is the lane's column) next to the 8 gray bytes of the Sobel window -- so the two instruction streams share the
+// wavefront's issue slots and a level costs one launch less.  Requires quadrant widths and origins that are multiples of
+// four (the host checks (W >> level) % 8 == 0).  A block = four bands of one strip; its histogram is folded after 16 rows
+// (10-bit fields: a column takes 2 lanes x 4 wavefronts x 4 pixels per row) and at the end, then added to the region's.
+template <bool EDGE>
+__device__ void hs_body(const uint8_t *__restrict__ g, const uint8_t *__restrict__ rgb, int W, const Region &r, int x0, int y0,
+                        int lane, int tid, int high, uint32_t *__restrict__ strong_flag, uint32_t *__restrict__ hist_reg, uint32_t *h,
+                        uint32_t *cnt)
+{
+    const int x = x0 + 4 * lane;
+    const bool rows_on = y0 < r.rows, counted = x + 4 <= r.cols;
+    const int y1 = min(y0 + kPreRows, r.rows);
+    const bool narrow = r.cols < 8;  // narrower than the window load: left to the full pass (as k_canny_strong)
+    // the 8 gray bytes loaded per row start at column xb of the region; window byte k sits sh[k] bits into them
+    const int xb = EDGE ? min(max(x - 1, 0), max(r.cols - 8, 0)) : x - 1;
+    uint32_t sh[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sh[k] = EDGE ? 8u * (uint32_t)(min(max(x - 1 + k, 0), r.cols - 1) - xb) : 0u;
+    const uint8_t *gbase = g + (size_t)r.y0 * W + r.x0 + xb;
+    const uint8_t *cbase = rgb + ((size_t)r.y0 * W + r.x0 + min(x, r.cols - 4)) * 3;
+    auto gload = [&](int y) -> uint64_t {
+        return *reinterpret_cast<const u64_unaligned *>(gbase + (size_t)min(max(y, 0), r.rows - 1) * W);
+    };
+    const uint32_t colb = (uint32_t)(tid & 31) * 4u;
+    char *hb = reinterpret_cast<char *>(h);
+    auto bump = [&](uint32_t moved, uint32_t inc) { atomicAdd(reinterpret_cast<uint32_t *>(hb + ((moved & 0x7f80u) | colb)), inc); };
+    constexpr uint32_t kR = 1u, kG = 1u << 10, kB = 1u << 20;
+    auto fold = [&]() {  // all threads; thread v folds the 32 columns of value v into the 32-bit totals and clears them
+        __syncthreads();
+        uint32_t cr = 0, cg = 0, cb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint4 *wq = reinterpret_cast<uint4 *>(&h[tid * 32 + 4 * ((tid + k) & 7)]);
+            const uint4 w = *wq;
+            *wq = make_uint4(0, 0, 0, 0);
+            cr += (w.x & 1023u) + (w.y & 1023u) + (w.z & 1023u) + (w.w & 1023u);
+            cg += ((w.x >> 10) & 1023u) + ((w.y >> 10) & 1023u) + ((w.z >> 10) & 1023u) + ((w.w >> 10) & 1023u);
+            cb += (w.x >> 20) + (w.y >> 20) + (w.z >> 20) + (w.w >> 20);
+        }
+        cnt[tid] += cr; cnt[256 + tid] += cg; cnt[512 + tid] += cb;
+        __syncthreads();
+    };
+    bool sobel = rows_on && !narrow && !__hip_atomic_load(strong_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (wavefront-uniform)
+    PreRow a{}, b{};
+    if (sobel) {
+        a = pre_row<EDGE>(gload(y0 - 1), sh);
+        b = pre_row<EDGE>(gload(y0), sh);
+    }
+    v2s m0 = {0, 0}, m1 = {0, 0};
+#pragma unroll 1
+    for (int blk = 0; blk < kPreRows / 8; ++blk) {  // the same trip count for the four wavefronts: fold() is a barrier
+        const int yb = y0 + 8 * blk;
+        if (rows_on && yb < y1) {
+            uint64_t w[8];
+            uint32_t c[8][3];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int yy = min(yb + i, y1 - 1);  // (past the band: the last row again, harmless)
+                w[i] = gload(yy + 1);
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(cbase + (size_t)yy * W * 3);
+                c[i][0] = q[0]; c[i][1] = q[1]; c[i][2] = q[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (yb + i < y1) {
+                    if (counted) {
+                        const uint32_t c0 = c[i][0], c1 = c[i][1], c2 = c[i][2];
+                        // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                        bump(c0 << 7, kR); bump(c0 >> 1, kG); bump(c0 >> 9, kB);
+                        bump(c0 >> 17, kR); bump(c1 << 7, kG); bump(c1 >> 1, kB);
+                        bump(c1 >> 9, kR); bump(c1 >> 17, kG); bump(c2 << 7, kB);
+                        bump(c2 >> 1, kR); bump(c2 >> 9, kG); bump(c2 >> 17, kB);
+                    }
+                    if (sobel) {
+                        const PreRow cc = pre_row<EDGE>(w[i], sh);
+                        const v2s dx0 = a.hd0 + b.hd0 + b.hd0 + cc.hd0, dx1 = a.hd1 + b.hd1 + b.hd1 + cc.hd1;
+                        const v2s dy0 = cc.hs0 - a.hs0, dy1 = cc.hs1 - a.hs1;
+                        m0 = __builtin_elementwise_max(m0, __builtin_elementwise_abs(dx0) + __builtin_elementwise_abs(dy0));
+                        m1 = __builtin_elementwise_max(m1, __builtin_elementwise_abs(dx1) + __builtin_elementwise_abs(dy1));
+                        a = b;
+                        b = cc;
+                    }
+                }
+            }
+        }
+        if (blk == 1) fold();
+    }
+    fold();
+    for (int i = tid; i < 768; i += 256)
+        if (cnt[i]) atomicAdd(&hist_reg[i], cnt[i]);
+    if (rows_on && narrow) {
+        if (lane == 0) *strong_flag = 1;
+        return;
+    }
+    union { v2s v; uint32_t u; } u0, u1;
+    u0.v = m0; u1.v = m1;
+    const int m[4] = {(int)(u0.u & 0xffffu), (int)(u0.u >> 16), (int)(u1.u & 0xffffu), (int)(u1.u >> 16)};
+    bool hot = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hot = hot || (x + j < r.cols && m[j] > high);
+    if (__ballot(hot) && lane == 0) *strong_flag = 1;
+}
+
+__global__ void __launch_bounds__(256) k_hist_strong(const uint8_t *__restrict__ in, const uint8_t *__restrict__ gray,
+                                                     const Region *__restrict__ regs, int H, int W, int strips, int high,
+                                                     uint32_t *__restrict__ strong, uint32_t *__restrict__ hist)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t h[256 * 32];
+    __shared__ uint32_t cnt[768];
+    const Region r = regs[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = blockIdx.x % strips, band = (blockIdx.x / strips) * 4 + wv;
+    const int x0 = strip * kPreCols, y0 = band * kPreRows;
+    if (r.rows <= 0 || r.cols < 4 || x0 >= r.cols || (int)(blockIdx.x / strips) * 4 * kPreRows >= r.rows) return;  // (block-uniform)
+    for (int i = tid; i < 256 * 32 / 4; i += 256) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 768; i += 256) cnt[i] = 0;
+    // (the first fold's barrier orders the clears before the first atomics of the OTHER wavefronts; this one for its own)
+    __syncthreads();
+    const uint8_t *g = gray + (size_t)r.img * H * W, *rgb = in + (size_t)r.img * H * W * 3;
+    const bool edge = !(x0 >= 1 && x0 + kPreCols + 3 <= r.cols);  // (block-uniform: the four wavefronts share the strip)
+    if (edge) hs_body<true>(g, rgb, W, r, x0, y0, lane, tid, high, strong + blockIdx.y, hist + (size_t)blockIdx.y * 768, h, cnt);
+    else hs_body<false>(g, rgb, W, r, x0, y0, lane, tid, high, strong + blockIdx.y, hist + (size_t)blockIdx.y * 768, h, cnt);
+}
+
 // lock-free union-find on tile-local indices in LDS (links point to the smaller index)
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *L, int i)
 {
@@ -869,6 +997,21 @@ int launch_gray_strong(const uint8_t *d_in, const int32_t *d_kind, uint8_t *d_gr
     gray_f32_coeffs(gray_shift, cr, cg, cb);
     UWIE_LAUNCH(k_gray_strong, dim3(strips * bandgroups, nreg), dim3(256), 0, st, d_in, d_kind, d_regions, s.H, s.W, strips, high,
                 cr, cg, cb, d_gray, bufs.strong);
+    UWIE_LAUNCH_CHECK();
+    return UWIE_OK;
+}
+
+// Levels >= 1 (the gray plane exists): quadrant histograms into d_hist ([nreg][768], accumulated) and the pre-pass flags of the
+// same regions in one sweep; the flags must be zero on entry (k_q_decide leaves them so), launch_canny then takes prepass_done.
+int launch_hist_strong(const uint8_t *d_in, const uint8_t *d_gray, Shape s, const Region *d_regions, int nreg, int max_rows,
+                       int max_cols, int high, uint32_t *d_hist, void *ws, hipStream_t st)
+{
+    Carver c(ws);
+    CannyBufs bufs = carve_canny(c, s);
+    UWIE_REQUIRE(max_cols % 4 == 0 && max_cols >= 4, "hist_strong: quadrant widths must be multiples of four");
+    const int strips = cdiv(max_cols, kPreCols), bandgroups = cdiv(cdiv(max_rows, kPreRows), 4);
+    UWIE_LAUNCH(k_hist_strong, dim3(strips * bandgroups, nreg), dim3(256), 0, st, d_in, d_gray, d_regions, s.H, s.W, strips, high,
+                bufs.strong, d_hist);
     UWIE_LAUNCH_CHECK();
     return UWIE_OK;
 }
