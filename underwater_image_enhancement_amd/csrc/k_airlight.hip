@@ -46,6 +46,30 @@ __global__ void k_init_blocks(Region *blk, int B, int H, int W)
     if (b < B) blk[b] = Region{b, 0, 0, H, W};
 }
 
+// The quadtree's set-up in one launch (round 4: k_init_blocks, k_make_quadrants and three memsets were five launches of ~5 us):
+// every image's block = its frame, the four quadrants of it, zeroed edge counters, pre-pass flags and level histograms.
+__global__ void __launch_bounds__(256) k_q_setup(Region *__restrict__ blk, Region *__restrict__ regs, uint32_t *__restrict__ edges,
+                                                 uint32_t *__restrict__ strong, uint32_t *__restrict__ hist, int B, int H, int W,
+                                                 int min_size)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, n = gridDim.x * 256;
+    for (int b = i; b < B; b += n) {
+        const Region k{b, 0, 0, H, W};
+        blk[b] = k;
+        const bool leaf = k.rows <= min_size || k.cols <= min_size;  // six_stadigy.py:76
+        const int mr = k.rows / 2, mc = k.cols / 2;                 // six_stadigy.py:85-86
+        Region q[4] = {{b, 0, 0, mr, mc}, {b, 0, mc, mr, W - mc}, {b, mr, 0, H - mr, mc}, {b, mr, mc, H - mr, W - mc}};
+        for (int j = 0; j < 4; ++j) {
+            if (leaf) q[j].rows = q[j].cols = 0;
+            regs[b * 4 + j] = q[j];
+            edges[b * 4 + j] = 0;
+            strong[b * 4 + j] = 0;
+        }
+    }
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist);  // [4 B][768] words: a multiple of four, 256-byte aligned (Carver)
+    for (int j = i; j < B * 768; j += n) h4[j] = make_uint4(0, 0, 0, 0);
+}
+
 __global__ void k_make_quadrants(const Region *__restrict__ blk, Region *__restrict__ regs, int B, int min_size)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1315,14 +1339,23 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
     LevelBufs L = carve_level(c, s);
     void *canny_ws = c.take<char>(canny_ws_bytes(s));
     const int B = s.B, nreg = 4 * B;
-    UWIE_LAUNCH(k_init_blocks, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, B, s.H, s.W);
-    UWIE_LAUNCH_CHECK();
+    const bool one_setup = tune().q_hist != 0 && tune().canny_prepass;  // (the routes that use all of what k_q_setup prepares)
+    if (one_setup) {
+        UWIE_LAUNCH(k_q_setup, dim3(std::min(1024, cdiv((long long)B * 768, 256))), dim3(256), 0, st, L.blk, L.regs, L.edges,
+                    canny_strong_flags(canny_ws, s), L.hist, B, s.H, s.W, min_size);
+        UWIE_LAUNCH_CHECK();
+    } else {
+        UWIE_LAUNCH(k_init_blocks, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, B, s.H, s.W);
+        UWIE_LAUNCH_CHECK();
+    }
     if (d_trace) UWIE_HIP_CHECK(hipMemsetAsync(d_trace, 0, (size_t)B * kMaxLevels * sizeof(TraceRec), st));
     const int maxChunks = max_chunks(s);
     int rmax = s.H, cmax = s.W;  // largest block any image can hold at this level
-    UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
-    UWIE_LAUNCH_CHECK();
-    UWIE_HIP_CHECK(hipMemsetAsync(L.edges, 0, sizeof(uint32_t) * nreg, st));
+    if (!one_setup) {
+        UWIE_LAUNCH(k_make_quadrants, dim3(cdiv(B, 64)), dim3(64), 0, st, L.blk, L.regs, B, min_size);
+        UWIE_LAUNCH_CHECK();
+        UWIE_HIP_CHECK(hipMemsetAsync(L.edges, 0, sizeof(uint32_t) * nreg, st));
+    }
     constexpr bool use_tail = true, fuse_gray = true;  // (the small levels in one launch; level 0 writes the gray plane)
     bool gray_pending = make_gray_shift != 0;
     {
@@ -1343,7 +1376,8 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
         // intervals; the exact kernels below return at once for every decided image.  tuning q_hist = 0: exact only.
         const bool use_hist = tune().q_hist != 0;
         if (use_hist) {
-            if (level == 0) UWIE_HIP_CHECK(hipMemsetAsync(L.hist, 0, sizeof(uint32_t) * (size_t)nreg * 768, st));  // (k_q_decide clears after use)
+            if (level == 0 && !one_setup)
+                UWIE_HIP_CHECK(hipMemsetAsync(L.hist, 0, sizeof(uint32_t) * (size_t)nreg * 768, st));  // (k_q_decide clears after use)
             // ~64 K pixels per block, at least ~2048 blocks when the job has them
             int nblk = std::max(1, cdiv((long long)qr * qc, 65536));
             while (nblk * 2 <= qr && (long long)nblk * nreg < 2048 && (long long)qr * qc / (nblk * 2) >= 8192) nblk *= 2;
@@ -1390,7 +1424,8 @@ int launch_airlight(uwie_ctx *ctx, const uint8_t *d_in, const int32_t *d_kind, u
                 gray_pending = false;
                 prepass_done = true;
             }
-            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0, prepass_done);
+            int rc = launch_canny(d_gray, s, L.regs, nreg, qr, qc, 50, 150, L.edges, nullptr, canny_ws, st, true, level > 0 || one_setup,
+                                  prepass_done);
             if (rc != UWIE_OK) return rc;
             UWIE_LAUNCH(k_q_decide, dim3(B), dim3(256), 0, st, L.blk, L.regs, (const uint32_t *)L.hist, L.edges, d_kind, min_size,
                         (d_trace || tune().q_hist == 2) ? 1 : 0, L.skip, canny_strong_flags(canny_ws, s),
