@@ -607,6 +607,27 @@ struct RawRing<0> {
     template <int S> __device__ __forceinline__ void set_at(uint32_t, uint32_t, uint32_t) {}
 };
 
+// Round 4, SPLIT_QUAD (k = 15): the staging lines hold QUAD sums instead of pair sums.  A lane's pair sum P[l] = s[2l] + s[2l+1]
+// meets its right neighbour's through one DPP wavefront shift (v_mov_b32_dpp wave_shl:1, no LDS), and what is staged is
+//     R[l] = P[l] + P[l+1]   (slots 2l .. 2l+3)        Z[l] = P[l] + s[2l+2]   (slots 2l .. 2l+2)
+// so the two windows of a lane are  o[0] = R[l] + R[l+2] + R[l+4] + Z[l+6]  and  o[1] = (s[2l+1] + P[l+1]) + R[l+2] + R[l+4] + R[l+6]:
+// four 16-byte LDS reads per plane pair where the pair sums took eight, the same two writes, the same 32 bytes per lane.
+// R[l] and U[l] = s[2l+1] + P[l+1] of the lane itself stay in registers from the staging to the next step's read phase
+// (the vertical sums do not change in between).
+#ifndef SPLIT_QUAD
+#define SPLIT_QUAD 1
+#endif
+__device__ __forceinline__ double dpp_next(double v)  // the value lane + 1 holds (0 in lane 63: only unstored slots read it)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint32_t dpp_next(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
 // Per window width: row buffers in flight and whether the raw rows of the window ride in registers.
 //   K = 15: b ring 60 + raw ring 30 registers, three buffers (the round-2 kernel);  K = 10: 40 + 20, five buffers;
 //   K = 20: the b ring alone takes 80 registers, so the leaving raw row is re-read (t0 row 4 B + guide 1 B per slot), four buffers
@@ -849,11 +870,42 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             o[1] = make_double2((v1.x + midx) + f0.x, (v1.y + midy) + f0.y);
         }
     };
+    // QUAD: lines of quad sums (see SPLIT_QUAD above); R and U of the lane's own slots ride in registers to the next read phase
+    constexpr bool QUAD = SPLIT_QUAD && (K & 1) && (M & 1) && M >= 5;
+    double2 R1 = make_double2(0.0, 0.0), U1 = R1, R2 = R1, U2 = R1;
+    uint2 RI = make_uint2(0u, 0u), UI = RI;
+    auto stage_quad = [&](double2 *line, double x0, double x1, double y0, double y1, double2 &Rk, double2 &Uk) {
+        const double2 P = make_double2(x0 + x1, y0 + y1);
+        const double2 Pn = make_double2(dpp_next(P.x), dpp_next(P.y));
+        const double2 v0n = make_double2(dpp_next(x0), dpp_next(y0));
+        Rk = make_double2(P.x + Pn.x, P.y + Pn.y);
+        Uk = make_double2(x1 + Pn.x, y1 + Pn.y);
+        line[0] = Rk;
+        line[SW] = make_double2(P.x + v0n.x, P.y + v0n.y);
+    };
+    auto window2q = [&](const double2 *rr, double2 Rk, double2 Uk, double2 (&o)[2]) {
+        double2 mid = rr[2];
+#pragma unroll
+        for (int d = 4; d <= M - 3; d += 2) { const double2 t = rr[d]; mid.x += t.x; mid.y += t.y; }
+        const double2 z = rr[SW + M - 1], rl = rr[M - 1];
+        o[0] = make_double2((Rk.x + mid.x) + z.x, (Rk.y + mid.y) + z.y);
+        o[1] = make_double2((Uk.x + mid.x) + rl.x, (Uk.y + mid.y) + rl.y);
+    };
     auto stage_v1 = [&]() {
-        const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
-        const_cast<double2 *>(vv1)[0] = make_double2(V1p[0], V1gp[0]);
-        const_cast<uint2 *>(pi)[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
-        const_cast<uint2 *>(vi)[0] = make_uint2(Sg[0], Sgg[0]);
+        if constexpr (QUAD) {
+            stage_quad(const_cast<double2 *>(pp1), V1p[0], V1p[1], V1gp[0], V1gp[1], R1, U1);
+            const uint2 P = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
+            const uint2 Pn = make_uint2(dpp_next(P.x), dpp_next(P.y));
+            RI = make_uint2(P.x + Pn.x, P.y + Pn.y);
+            UI = make_uint2(Sg[1] + Pn.x, Sgg[1] + Pn.y);
+            const_cast<uint2 *>(pi)[0] = RI;
+            const_cast<uint2 *>(vi)[0] = make_uint2(P.x + dpp_next(Sg[0]), P.y + dpp_next(Sgg[0]));
+        } else {
+            const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
+            const_cast<double2 *>(vv1)[0] = make_double2(V1p[0], V1gp[0]);
+            const_cast<uint2 *>(pi)[0] = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
+            const_cast<uint2 *>(vi)[0] = make_uint2(Sg[0], Sgg[0]);
+        }
     };
 
     // One step i: C(i-2) [not in the warm period], B(i-1) on ring slot S, A(i).
@@ -863,11 +915,22 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         char *ring_p = lds + a_ring + (uint32_t)((S >= AR ? S - AR : 0) * NLp * EB);
         // ================= read phase
         double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
-        if constexpr (!WARM) window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
+        if constexpr (!WARM) {
+            if constexpr (QUAD) window2q(pp2, R2, U2, oab);
+            else window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
+        }
         double2 opg[2];  // {sum p, sum g*p}
-        window2(pp1, vv1, make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]), make_double2(V1p[1], V1gp[1]), opg);
+        if constexpr (QUAD) window2q(pp1, R1, U1, opg);
+        else window2(pp1, vv1, make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]), make_double2(V1p[1], V1gp[1]), opg);
         uint32_t oG[2], oGG[2];
-        {
+        if constexpr (QUAD) {
+            uint2 mid = pi[2];
+#pragma unroll
+            for (int d = 4; d <= M - 3; d += 2) { mid.x += pi[d].x; mid.y += pi[d].y; }
+            const uint2 z = vi[M - 1], rl = pi[M - 1];
+            oG[0] = RI.x + mid.x + z.x;   oGG[0] = RI.y + mid.y + z.y;
+            oG[1] = UI.x + mid.x + rl.x;  oGG[1] = UI.y + mid.y + rl.y;
+        } else {
             const uint2 *ps = pi;
             uint2 m0 = ps[1], m1 = ps[2];
 #pragma unroll
@@ -960,8 +1023,12 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         // ================= write phase
         pipe_sync();
         stage_v1();
-        const_cast<double2 *>(pp2)[0] = make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]);
-        const_cast<double2 *>(vv2)[0] = make_double2(V2a[0], V2b[0]);
+        if constexpr (QUAD) {
+            stage_quad(const_cast<double2 *>(pp2), V2a[0], V2a[1], V2b[0], V2b[1], R2, U2);
+        } else {
+            const_cast<double2 *>(pp2)[0] = make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]);
+            const_cast<double2 *>(vv2)[0] = make_double2(V2a[0], V2b[0]);
+        }
         if constexpr (S >= AR) *reinterpret_cast<double2 *>(ring_p) = make_double2(av[0], av[1]);
         pipe_sync();
     };
@@ -979,6 +1046,9 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
                             // step i + NB - 1, whose C phase stores row i + NB - 3 - Lb (unused before the first normal step)
     int yo = y_lo;          // row the next normal step stores
     auto issue = [&](In &fill) {
+        // (the row counters pass through an empty asm: without it instruction selection may emit the row arithmetic of a whole
+        // ring period ahead of its first step -- 45 live scalars, spilled to vector lanes, then to scratch)
+        asm volatile("" : "+s"(re), "+s"(gr), "+s"(yo));
         const uint32_t er = (uint32_t)pipe_reflect(re, H), lr = (uint32_t)pipe_reflect(re - RC, H);
         const uint32_t og = (uint32_t)min(max(gr, 0), H - 1);
         load_rows(er * pitch_t, er * pitch_g, lr * pitch_t, lr * pitch_g, og * pitch_g, fill);
