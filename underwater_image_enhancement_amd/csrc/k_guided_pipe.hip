@@ -617,6 +617,9 @@ struct RawRing<0> {
 #ifndef SPLIT_QUAD
 #define SPLIT_QUAD 1
 #endif
+#ifndef SPLIT_MUL24
+#define SPLIT_MUL24 1  // 0: v_mul_lo_u32 for the variance numerator (A/B builds)
+#endif
 __device__ __forceinline__ double dpp_next(double v)  // the value lane + 1 holds (0 in lane 63: only unstored slots read it)
 {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
@@ -968,7 +971,11 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         double av[2], bv[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const uint32_t nvar = oGG[c] * (uint32_t)(K * K) - oG[c] * oG[c];  // (255 K^2)^2 var: exact
+            // (255 K^2)^2 var, exact.  k <= 16: both factors stay below 2^24 (sum g <= 255 K^2, sum g^2 <= 255^2 K^2) and the products
+            // below 2^32, so the full-rate 24-bit multiplier serves (v_mul_lo_u32 is a quarter-rate instruction)
+            constexpr bool MUL24 = SPLIT_MUL24 && 255 * 255 * K * K < (1 << 24);  // (k = 20: sum g^2 needs 25 bits; the difference is exact mod 2^32)
+            const uint32_t nvar = MUL24 ? __umul24(oGG[c], (uint32_t)(K * K)) - __umul24(oG[c], oG[c])
+                                        : oGG[c] * (uint32_t)(K * K) - oG[c] * oG[c];
             const double D = fma((double)nvar, 1.0 / 255.0, cs.Ek);            // 255 K^4 (var + eps)
             const double gd = (double)oG[c];
             const double ncov = fma(K2, opg[c].y, -(gd * opg[c].x));           // 255 K^4 cov
