@@ -572,10 +572,10 @@ struct RegRing<0> {
 // The last RC raw rows of a lane's two slots (transmission as float32 bits, the two guide bytes packed), in registers: the
 // row that leaves the first box filter's window is the row that entered RC steps earlier, so it is never re-read from
 // memory (those re-reads missed L2 and doubled the kernel's HBM traffic).
-template <int N>
+template <int N, bool G>  // G: the guide bytes ride along
 struct RawRing {
     uint32_t t0, t1, g;
-    RawRing<N - 1> rest;
+    RawRing<N - 1, G> rest;
     template <int S>
     __device__ __forceinline__ void swap_at(uint32_t &a0, uint32_t &a1, uint32_t &gg)
     {
@@ -583,11 +583,11 @@ struct RawRing {
             const uint32_t o0 = t0, o1 = t1;
             t0 = a0; t1 = a1;
             a0 = o0; a1 = o1;
-#if !defined(SPLIT_RAW_G) || SPLIT_RAW_G
-            const uint32_t og = g;
-            g = gg;
-            gg = og;
-#endif
+            if constexpr (G) {
+                const uint32_t og = g;
+                g = gg;
+                gg = og;
+            }
         } else rest.template swap_at<S - 1>(a0, a1, gg);
     }
     template <int S>
@@ -595,14 +595,12 @@ struct RawRing {
     {
         if constexpr (S == 0) {
             t0 = a0; t1 = a1;
-#if !defined(SPLIT_RAW_G) || SPLIT_RAW_G
-            g = gg;
-#endif
+            if constexpr (G) g = gg;
         } else rest.template set_at<S - 1>(a0, a1, gg);
     }
 };
-template <>
-struct RawRing<0> {
+template <bool G>
+struct RawRing<0, G> {
     template <int S> __device__ __forceinline__ void swap_at(uint32_t &, uint32_t &, uint32_t &) {}
     template <int S> __device__ __forceinline__ void set_at(uint32_t, uint32_t, uint32_t) {}
 };
@@ -615,7 +613,7 @@ struct RawRing<0> {
 // R[l] and U[l] = s[2l+1] + P[l+1] of the lane itself stay in registers from the staging to the next step's read phase
 // (the vertical sums do not change in between).
 #ifndef SPLIT_QUAD
-#define SPLIT_QUAD 1
+#define SPLIT_QUAD 2
 #endif
 #ifndef SPLIT_MUL24
 #define SPLIT_MUL24 1  // 0: v_mul_lo_u32 for the variance numerator (A/B builds)
@@ -736,12 +734,17 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
 
     // what the loads return, untouched (unpacked at the point of use: an early unpack would wait for the load at once)
 #ifndef SPLIT_RAW_G
-#define SPLIT_RAW_G 0  // 1: the guide bytes of the last RC rows ride in the register ring too (3.13 ms at 4K x 64: register pressure); 0: the leaving row's two bytes are re-read (3.03 ms)
+// 1: the guide bytes of the last RC rows ride in the register ring too; 0: the leaving row's two bytes are re-read.  Rounds 2 - 3:
+// 3.13 ms against 3.03 at 4K x 64 (register pressure).  Round 4, with the quad-sum staging (209 registers without the bytes):
+// 2.45 / 2.50 ms against 2.49 / 2.55 -- one load and its row arithmetic less per step.
+#define SPLIT_RAW_G 1
 #endif
+    // (k = 15 without the fused transmission only: k = 10 with its five row buffers and the fused kernel spill with them)
+    constexpr bool RAWG = SPLIT_RAW_G && RAWREG && K == 15 && !FUSE;
     struct In {
         uint32_t te[2];         // entering raw row: float bits of the two slots
         uint32_t ge[2], go[2];  // its guide bytes / the guide bytes of the output row; !EDGE: [0] holds both bytes
-        uint32_t gl[2];         // (SPLIT_RAW_G == 0) guide bytes of the leaving row
+        uint32_t gl[2];         // (!RAWG) guide bytes of the leaving row
         uint32_t tl[2];         // (!RAWREG) leaving raw row
     };
     auto byte_of = [](const uint32_t (&v)[2], int c) { return EDGE ? v[c] : (c == 0 ? (v[0] & 255u) : (v[0] >> 8)); };
@@ -756,13 +759,13 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
                 in.tl[1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[1], ol_t, 0);
             }
         }
-#if !SPLIT_RAW_G
-        if constexpr (!EDGE) in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
-        else {
-            in.gl[0] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[0], ol_g, 0);
-            in.gl[1] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[1], ol_g, 0);
+        if constexpr (!RAWG) {
+            if constexpr (!EDGE) in.gl[0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rG, ofs_g[0], ol_g, 0);
+            else {
+                in.gl[0] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[0], ol_g, 0);
+                in.gl[1] = (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rG, ofs_g[1], ol_g, 0);
+            }
         }
-#endif
         if constexpr (!EDGE) {
             if constexpr (FUSE) {  // the two pixels' six bytes: a dword (2-byte aligned: the column is even) and a short
                 in.te[0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rT, ofs_t[0], oe_t, 0);
@@ -809,7 +812,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     double V1p[2] = {0.0, 0.0}, V1gp[2] = {0.0, 0.0};
     uint32_t Sg[2] = {0, 0}, Sgg[2] = {0, 0};
     double V2a[2] = {0.0, 0.0}, V2b[2] = {0.0, 0.0};
-    RawRing<RAWREG ? RC : 0> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
+    RawRing<RAWREG ? RC : 0, RAWG> raw;  // slot j <-> raw row r_lo - a + j (mod RC): the slot of the row that leaves at a step is the step's slot
     auto prologue_row = [&](auto j_tag) {
         constexpr int J = decltype(j_tag)::value;
         const uint32_t row = (uint32_t)pipe_reflect(r_lo - a + J, H);  // rows above / below the image: BORDER_REFLECT_101
@@ -877,22 +880,36 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
     constexpr bool QUAD = SPLIT_QUAD && (K & 1) && (M & 1) && M >= 5;
     double2 R1 = make_double2(0.0, 0.0), U1 = R1, R2 = R1, U2 = R1;
     uint2 RI = make_uint2(0u, 0u), UI = RI;
+    // SPLIT_QUAD == 2: the second line holds the lane's ODD slot s[2l+1] as it is (no second DPP shift, no Z); the even window
+    // follows from the odd one, o[0] = o[1] - s[2l+15] + s[2l]  (the sums of p and g p are exact in float64, so the order does
+    // not matter there; for a and b one subtraction rounds like one addition: both sums have the window's magnitude)
+    constexpr bool QSUB = SPLIT_QUAD == 2;
     auto stage_quad = [&](double2 *line, double x0, double x1, double y0, double y1, double2 &Rk, double2 &Uk) {
         const double2 P = make_double2(x0 + x1, y0 + y1);
         const double2 Pn = make_double2(dpp_next(P.x), dpp_next(P.y));
-        const double2 v0n = make_double2(dpp_next(x0), dpp_next(y0));
         Rk = make_double2(P.x + Pn.x, P.y + Pn.y);
         Uk = make_double2(x1 + Pn.x, y1 + Pn.y);
         line[0] = Rk;
-        line[SW] = make_double2(P.x + v0n.x, P.y + v0n.y);
+        if constexpr (QSUB) {
+            line[SW] = make_double2(x1, y1);
+        } else {
+            const double2 v0n = make_double2(dpp_next(x0), dpp_next(y0));
+            line[SW] = make_double2(P.x + v0n.x, P.y + v0n.y);
+        }
     };
-    auto window2q = [&](const double2 *rr, double2 Rk, double2 Uk, double2 (&o)[2]) {
+    auto window2q = [&](const double2 *rr, double2 Rk, double2 Uk, double x0, double y0, double2 (&o)[2]) {
         double2 mid = rr[2];
 #pragma unroll
         for (int d = 4; d <= M - 3; d += 2) { const double2 t = rr[d]; mid.x += t.x; mid.y += t.y; }
-        const double2 z = rr[SW + M - 1], rl = rr[M - 1];
-        o[0] = make_double2((Rk.x + mid.x) + z.x, (Rk.y + mid.y) + z.y);
+        const double2 rl = rr[M - 1];
         o[1] = make_double2((Uk.x + mid.x) + rl.x, (Uk.y + mid.y) + rl.y);
+        if constexpr (QSUB) {
+            const double2 w = rr[SW + M];
+            o[0] = make_double2((o[1].x - w.x) + x0, (o[1].y - w.y) + y0);
+        } else {
+            const double2 z = rr[SW + M - 1];
+            o[0] = make_double2((Rk.x + mid.x) + z.x, (Rk.y + mid.y) + z.y);
+        }
     };
     auto stage_v1 = [&]() {
         if constexpr (QUAD) {
@@ -902,7 +919,8 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             RI = make_uint2(P.x + Pn.x, P.y + Pn.y);
             UI = make_uint2(Sg[1] + Pn.x, Sgg[1] + Pn.y);
             const_cast<uint2 *>(pi)[0] = RI;
-            const_cast<uint2 *>(vi)[0] = make_uint2(P.x + dpp_next(Sg[0]), P.y + dpp_next(Sgg[0]));
+            if constexpr (QSUB) const_cast<uint2 *>(vi)[0] = make_uint2(Sg[1], Sgg[1]);
+            else const_cast<uint2 *>(vi)[0] = make_uint2(P.x + dpp_next(Sg[0]), P.y + dpp_next(Sgg[0]));
         } else {
             const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
             const_cast<double2 *>(vv1)[0] = make_double2(V1p[0], V1gp[0]);
@@ -919,20 +937,26 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         // ================= read phase
         double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
         if constexpr (!WARM) {
-            if constexpr (QUAD) window2q(pp2, R2, U2, oab);
+            if constexpr (QUAD) window2q(pp2, R2, U2, V2a[0], V2b[0], oab);
             else window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
         }
         double2 opg[2];  // {sum p, sum g*p}
-        if constexpr (QUAD) window2q(pp1, R1, U1, opg);
+        if constexpr (QUAD) window2q(pp1, R1, U1, V1p[0], V1gp[0], opg);
         else window2(pp1, vv1, make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]), make_double2(V1p[1], V1gp[1]), opg);
         uint32_t oG[2], oGG[2];
         if constexpr (QUAD) {
             uint2 mid = pi[2];
 #pragma unroll
             for (int d = 4; d <= M - 3; d += 2) { mid.x += pi[d].x; mid.y += pi[d].y; }
-            const uint2 z = vi[M - 1], rl = pi[M - 1];
-            oG[0] = RI.x + mid.x + z.x;   oGG[0] = RI.y + mid.y + z.y;
+            const uint2 rl = pi[M - 1];
             oG[1] = UI.x + mid.x + rl.x;  oGG[1] = UI.y + mid.y + rl.y;
+            if constexpr (QSUB) {
+                const uint2 w = vi[M];
+                oG[0] = oG[1] - w.x + Sg[0];  oGG[0] = oGG[1] - w.y + Sgg[0];
+            } else {
+                const uint2 z = vi[M - 1];
+                oG[0] = RI.x + mid.x + z.x;   oGG[0] = RI.y + mid.y + z.y;
+            }
         } else {
             const uint2 *ps = pi;
             uint2 m0 = ps[1], m1 = ps[2];
@@ -1014,9 +1038,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         uint32_t lt[2] = {tbe[0], tbe[1]}, lg = EDGE ? (in.ge[0] | (in.ge[1] << 8)) : in.ge[0];
         if constexpr (RAWREG) raw.template swap_at<S>(lt[0], lt[1], lg);
         else { lt[0] = in.tl[0]; lt[1] = in.tl[1]; }
-#if !SPLIT_RAW_G
-        lg = EDGE ? (in.gl[0] | (in.gl[1] << 8)) : in.gl[0];
-#endif
+        if constexpr (!RAWG) lg = EDGE ? (in.gl[0] | (in.gl[1] << 8)) : in.gl[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const double pe = (double)__uint_as_float(tbe[c]), pl = (double)__uint_as_float(lt[c]);
