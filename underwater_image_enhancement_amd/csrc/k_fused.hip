@@ -484,6 +484,8 @@ __global__ void __launch_bounds__(256) k_restore_rank(RestoreSrc S, int npx, Lin
     // next group): written as `if (have) load`, the loads sat in a block of their own whose join copies their registers -- the
     // ISA showed s_waitcnt vmcnt right behind them, i.e. every trip waited for the "prefetch" it had just issued (k_chunk_hist
     // had the same defect in round 3).
+    // (Two trips of loads in flight instead of one -- 90 registers, still five wavefronts per SIMD -- measured 1.307 / 1.421 ms against
+    // 1.306 / 1.411 at 4K x 64: the sweep already moves 8.4 GB at 6.4 TB/s, its loads are not what it waits for.)
     uint32_t w_nx[3] = {0, 0, 0};
     double tv_nx[4] = {1.0, 1.0, 1.0, 1.0};
     bool have_nx = false;
