@@ -605,15 +605,13 @@ struct RawRing<0, G> {
     template <int S> __device__ __forceinline__ void set_at(uint32_t, uint32_t, uint32_t) {}
 };
 
-// Round 4, SPLIT_QUAD (k = 15): the staging lines hold QUAD sums instead of pair sums.  A lane's pair sum P[l] = s[2l] + s[2l+1]
-// meets its right neighbour's through one DPP wavefront shift (v_mov_b32_dpp wave_shl:1, no LDS), and what is staged is
-//     R[l] = P[l] + P[l+1]   (slots 2l .. 2l+3)        Z[l] = P[l] + s[2l+2]   (slots 2l .. 2l+2)
-// so the two windows of a lane are  o[0] = R[l] + R[l+2] + R[l+4] + Z[l+6]  and  o[1] = (s[2l+1] + P[l+1]) + R[l+2] + R[l+4] + R[l+6]:
-// four 16-byte LDS reads per plane pair where the pair sums took eight, the same two writes, the same 32 bytes per lane.
-// R[l] and U[l] = s[2l+1] + P[l+1] of the lane itself stay in registers from the staging to the next step's read phase
-// (the vertical sums do not change in between).
+// Round 4, SPLIT_QUAD: the staging lines hold QUAD sums instead of pair sums.  A lane's pair sum P[l] = s[2l] + s[2l+1] meets its
+// right neighbour's through one DPP wavefront shift (v_mov_b32_dpp wave_shl:1, no LDS); what is staged is R[l] = P[l] + P[l+1]
+// (slots 2l .. 2l+3) and one of the lane's own slots, and a window is a few quad sums two lanes apart -- k = 15: four 16-byte LDS
+// reads per plane pair where the pair sums took eight, k = 20: five for ten, k = 10: three for five; the same two writes, the same
+// 32 bytes per lane (split_body: stage_q / window_q).  SPLIT_QUAD = 0 keeps the pair sums (A/B builds).
 #ifndef SPLIT_QUAD
-#define SPLIT_QUAD 2
+#define SPLIT_QUAD 1
 #endif
 #ifndef SPLIT_MUL24
 #define SPLIT_MUL24 1  // 0: v_mul_lo_u32 for the variance numerator (A/B builds)
@@ -628,6 +626,12 @@ __device__ __forceinline__ uint32_t dpp_next(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
+__device__ __forceinline__ double2 q_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 q_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 q_next(double2 v) { return make_double2(dpp_next(v.x), dpp_next(v.y)); }
+__device__ __forceinline__ uint2 q_add(uint2 a, uint2 b) { return make_uint2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ uint2 q_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ uint2 q_next(uint2 v) { return make_uint2(dpp_next(v.x), dpp_next(v.y)); }
 
 // Per window width: row buffers in flight and whether the raw rows of the window ride in registers.
 //   K = 15: b ring 60 + raw ring 30 registers, three buffers (the round-2 kernel);  K = 10: 40 + 20, five buffers;
@@ -876,51 +880,59 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
             o[1] = make_double2((v1.x + midx) + f0.x, (v1.y + midy) + f0.y);
         }
     };
-    // QUAD: lines of quad sums (see SPLIT_QUAD above); R and U of the lane's own slots ride in registers to the next read phase
-    constexpr bool QUAD = SPLIT_QUAD && (K & 1) && (M & 1) && M >= 5;
-    double2 R1 = make_double2(0.0, 0.0), U1 = R1, R2 = R1, U2 = R1;
-    uint2 RI = make_uint2(0u, 0u), UI = RI;
-    // SPLIT_QUAD == 2: the second line holds the lane's ODD slot s[2l+1] as it is (no second DPP shift, no Z); the even window
-    // follows from the odd one, o[0] = o[1] - s[2l+15] + s[2l]  (the sums of p and g p are exact in float64, so the order does
-    // not matter there; for a and b one subtraction rounds like one addition: both sums have the window's magnitude)
-    constexpr bool QSUB = SPLIT_QUAD == 2;
-    auto stage_quad = [&](double2 *line, double x0, double x1, double y0, double y1, double2 &Rk, double2 &Uk) {
-        const double2 P = make_double2(x0 + x1, y0 + y1);
-        const double2 Pn = make_double2(dpp_next(P.x), dpp_next(P.y));
-        Rk = make_double2(P.x + Pn.x, P.y + Pn.y);
-        Uk = make_double2(x1 + Pn.x, y1 + Pn.y);
-        line[0] = Rk;
-        if constexpr (QSUB) {
-            line[SW] = make_double2(x1, y1);
+    // QUAD: lines of quad sums (see SPLIT_QUAD above).  s0 / s1: a lane's even / odd slot, P = s0 + s1, R[l] = P[l] + P[l+1]; the second
+    // line holds the slot that the window one column further on gains (odd K: the odd slot, even K: the even one) as it is.
+    //   k = 15 (M = 7):  o1 = (s1 + P[l+1]) + R[l+2] + R[l+4] + R[l+6],   o0 = o1 - s1[l+7] + s0       keep = s1 + P[l+1]
+    //   k = 20 (M = 10): o0 = R[l] + R[l+2] + R[l+4] + R[l+6] + R[l+8],   o1 = o0 - s0 + s0[l+10]      keep = R[l]
+    //   k = 10 (M = 5):  o0 = P[l] + R[l+1] + R[l+3],                     o1 = s1 + R[l+1] + R[l+3] + s0[l+5]
+    // (the sums of p and g p are exact in float64, so the order does not matter there; for a and b one subtraction rounds like one
+    // addition: both sums have the window's magnitude).  keep rides in registers from the staging to the next step's read phase:
+    // the vertical sums do not change in between.
+    // (k = 10 keeps its pair sums: three reads for five measured 0.61 / 0.62 ms against 0.60 / 0.60 at 4K x 16; k = 20: 0.90 -> 0.83)
+    constexpr bool QUAD = SPLIT_QUAD != 0 && ((K & 1) || !(M & 1));
+    static_assert(!QUAD || !(K & 1) || (M & 1), "odd windows: an odd number of pair sums on either side of the lane's own");
+    double2 keep1 = make_double2(0.0, 0.0), keep2 = keep1;
+    uint2 keepI = make_uint2(0u, 0u);
+    auto stage_q = [&](auto *line, auto s0, auto s1, auto &keep) {
+        const auto P = q_add(s0, s1);
+        const auto Pn = q_next(P);
+        const auto R = q_add(P, Pn);
+        line[0] = R;
+        if constexpr (K & 1) {
+            line[SW] = s1;
+            keep = q_add(s1, Pn);
         } else {
-            const double2 v0n = make_double2(dpp_next(x0), dpp_next(y0));
-            line[SW] = make_double2(P.x + v0n.x, P.y + v0n.y);
+            line[SW] = s0;
+            keep = R;
         }
     };
-    auto window2q = [&](const double2 *rr, double2 Rk, double2 Uk, double x0, double y0, double2 (&o)[2]) {
-        double2 mid = rr[2];
+    auto window_q = [&](const auto *rr, auto keep, auto s0, auto s1, auto *o) {
+        using T = decltype(keep);
+        const T w = rr[SW + M];
+        if constexpr (K & 1) {
+            T mid = rr[2];
 #pragma unroll
-        for (int d = 4; d <= M - 3; d += 2) { const double2 t = rr[d]; mid.x += t.x; mid.y += t.y; }
-        const double2 rl = rr[M - 1];
-        o[1] = make_double2((Uk.x + mid.x) + rl.x, (Uk.y + mid.y) + rl.y);
-        if constexpr (QSUB) {
-            const double2 w = rr[SW + M];
-            o[0] = make_double2((o[1].x - w.x) + x0, (o[1].y - w.y) + y0);
+            for (int d = 4; d <= M - 3; d += 2) mid = q_add(mid, rr[d]);
+            o[1] = q_add(q_add(keep, mid), rr[M - 1]);
+            o[0] = q_add(q_sub(o[1], w), s0);
+        } else if constexpr (!(M & 1)) {
+            T mid = rr[2];
+#pragma unroll
+            for (int d = 4; d <= M - 2; d += 2) mid = q_add(mid, rr[d]);
+            o[0] = q_add(keep, mid);
+            o[1] = q_add(q_sub(o[0], s0), w);
         } else {
-            const double2 z = rr[SW + M - 1];
-            o[0] = make_double2((Rk.x + mid.x) + z.x, (Rk.y + mid.y) + z.y);
+            T mid = rr[1];
+#pragma unroll
+            for (int d = 3; d <= M - 2; d += 2) mid = q_add(mid, rr[d]);
+            o[0] = q_add(q_add(s0, s1), mid);
+            o[1] = q_add(q_add(s1, mid), w);
         }
     };
     auto stage_v1 = [&]() {
         if constexpr (QUAD) {
-            stage_quad(const_cast<double2 *>(pp1), V1p[0], V1p[1], V1gp[0], V1gp[1], R1, U1);
-            const uint2 P = make_uint2(Sg[0] + Sg[1], Sgg[0] + Sgg[1]);
-            const uint2 Pn = make_uint2(dpp_next(P.x), dpp_next(P.y));
-            RI = make_uint2(P.x + Pn.x, P.y + Pn.y);
-            UI = make_uint2(Sg[1] + Pn.x, Sgg[1] + Pn.y);
-            const_cast<uint2 *>(pi)[0] = RI;
-            if constexpr (QSUB) const_cast<uint2 *>(vi)[0] = make_uint2(Sg[1], Sgg[1]);
-            else const_cast<uint2 *>(vi)[0] = make_uint2(P.x + dpp_next(Sg[0]), P.y + dpp_next(Sgg[0]));
+            stage_q(const_cast<double2 *>(pp1), make_double2(V1p[0], V1gp[0]), make_double2(V1p[1], V1gp[1]), keep1);
+            stage_q(const_cast<uint2 *>(pi), make_uint2(Sg[0], Sgg[0]), make_uint2(Sg[1], Sgg[1]), keepI);
         } else {
             const_cast<double2 *>(pp1)[0] = make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]);
             const_cast<double2 *>(vv1)[0] = make_double2(V1p[0], V1gp[0]);
@@ -937,26 +949,18 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         // ================= read phase
         double2 oab[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};  // {sum a, sum b} of the two slots
         if constexpr (!WARM) {
-            if constexpr (QUAD) window2q(pp2, R2, U2, V2a[0], V2b[0], oab);
+            if constexpr (QUAD) window_q(pp2, keep2, make_double2(V2a[0], V2b[0]), make_double2(V2a[1], V2b[1]), oab);
             else window2(pp2, vv2, make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]), make_double2(V2a[1], V2b[1]), oab);
         }
         double2 opg[2];  // {sum p, sum g*p}
-        if constexpr (QUAD) window2q(pp1, R1, U1, V1p[0], V1gp[0], opg);
+        if constexpr (QUAD) window_q(pp1, keep1, make_double2(V1p[0], V1gp[0]), make_double2(V1p[1], V1gp[1]), opg);
         else window2(pp1, vv1, make_double2(V1p[0] + V1p[1], V1gp[0] + V1gp[1]), make_double2(V1p[1], V1gp[1]), opg);
         uint32_t oG[2], oGG[2];
         if constexpr (QUAD) {
-            uint2 mid = pi[2];
-#pragma unroll
-            for (int d = 4; d <= M - 3; d += 2) { mid.x += pi[d].x; mid.y += pi[d].y; }
-            const uint2 rl = pi[M - 1];
-            oG[1] = UI.x + mid.x + rl.x;  oGG[1] = UI.y + mid.y + rl.y;
-            if constexpr (QSUB) {
-                const uint2 w = vi[M];
-                oG[0] = oG[1] - w.x + Sg[0];  oGG[0] = oGG[1] - w.y + Sgg[0];
-            } else {
-                const uint2 z = vi[M - 1];
-                oG[0] = RI.x + mid.x + z.x;   oGG[0] = RI.y + mid.y + z.y;
-            }
+            uint2 oi[2];
+            window_q(pi, keepI, make_uint2(Sg[0], Sgg[0]), make_uint2(Sg[1], Sgg[1]), oi);
+            oG[0] = oi[0].x; oGG[0] = oi[0].y;
+            oG[1] = oi[1].x; oGG[1] = oi[1].y;
         } else {
             const uint2 *ps = pi;
             uint2 m0 = ps[1], m1 = ps[2];
@@ -1053,7 +1057,7 @@ __device__ __forceinline__ void split_body(const uint8_t *__restrict__ gray, con
         pipe_sync();
         stage_v1();
         if constexpr (QUAD) {
-            stage_quad(const_cast<double2 *>(pp2), V2a[0], V2a[1], V2b[0], V2b[1], R2, U2);
+            stage_q(const_cast<double2 *>(pp2), make_double2(V2a[0], V2b[0]), make_double2(V2a[1], V2b[1]), keep2);
         } else {
             const_cast<double2 *>(pp2)[0] = make_double2(V2a[0] + V2a[1], V2b[0] + V2b[1]);
             const_cast<double2 *>(vv2)[0] = make_double2(V2a[0], V2b[0]);
