@@ -715,8 +715,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS == 2
         const uint32_t iz = (__umul24(Rg, f6) + __umul24(Gg, f7) + __umul24(Bg, f8) + 2048u) >> 12;
         const int fX = s_cbrt[ix], fY = s_cbrt[iy], fZ = s_cbrt[iz];
         // saturate_cast<uchar>(x >> 15) as clamp-then-shift: written shift-then-clamp, two adjacent values become one
-        // v_ashr_pk_u8_i32 (new on gfx950), whose result did not match on the hardware (round 3: a and b of every fourth
-        // pixel came out wrong); the clamp keeps x in [0, 2^23), so a logical shift finishes the job
+        // v_ashr_pk_u8_i32 (new on gfx950), which writes the low 16 bits of its destination only while this toolchain uses the
+        // register as a zero-extended word (profiles/microbench/ashr_pk.hip; round 3: a and b of every fourth pixel came out
+        // wrong); the clamp keeps x in [0, 2^23), so a logical shift finishes the job
         auto sat15 = [](int x) { return (uint32_t)min(max(x, 0), (256 << 15) - 1) >> 15; };
         L = sat15(__mul24(Lscale, fY) + (Lshift + (1 << 14)));
         a = sat15(__mul24(500, fX - fY) + (128 * (1 << 15) + (1 << 14)));
@@ -1421,8 +1422,9 @@ int launch_restore_planar_hist(const uint8_t *d_in, const int32_t *d_kind, const
 int launch_restore_rank(const RestoreSrc &src, Shape s, const SelectPlan &plan, hipStream_t st)
 {
     UWIE_REQUIRE(!src.t32 && plan.nq <= 2 && plan.predicted && s.npx() >= 4, "restore_rank: float64 transmission, two predicted percentiles");
-    // 25.5 KB of LDS per block.  Blocks per frame as for the histogram sweep (several full rounds of the chip).
-    int nblk = cdiv(12288, s.B);
+    // 28.8 KB of LDS per block: five blocks per CU, 1280 on the chip.  Four whole rounds of them per call (the histogram
+    // sweep's 12288 blocks were 9.6 rounds, the last one 60 % full: 1.43 -> 1.37 ms at 4K x 64, A/B/C with 2560 / 3840 / 5120).
+    int nblk = cdiv(5120, s.B);
     nblk = nblk < 16 ? 16 : nblk > 384 ? 384 : nblk;
     const int need = cdiv((long long)s.npx(), 1024);
     if (nblk > need) nblk = need;
@@ -1502,7 +1504,10 @@ int launch_tail_clahe(uwie_ctx *ctx, const float *d_planar, const float *d_pct, 
     UWIE_LAUNCH_CHECK();
     // row chunks per interpolation cell: enough blocks to fill the chip, at least ~16 rows each
     const int cells = (tx + 1) * (ty + 1);
-    int nchunk = cdiv(25920, cells * s.B);  // ~12 rounds of the 2048 resident blocks
+#ifndef UWIE_APPLY_TOTAL
+#define UWIE_APPLY_TOTAL 25920
+#endif
+    int nchunk = cdiv(UWIE_APPLY_TOTAL, cells * s.B);  // ~14 rounds of the 1792 resident blocks (7 per CU by registers)
     nchunk = std::max(1, std::min(nchunk, std::max(1, g.th / 16)));
     const auto k_clahe_apply_u8 = k_clahe_apply_out<false, false>;  // (names as the profiler reports them)
     const auto k_clahe_apply_f32 = k_clahe_apply_out<false, true>;
