@@ -48,6 +48,6 @@ python3 profiles/summarize_sq.py $O/sq_${TAG}_guided guided > $O/${TAG}_guided_s
 rm -rf $O/sq_${TAG}_guided $O/sq_${TAG}_guided.*.log
 python3 profiles/time_exact.py 2160 3840 64 > $O/${TAG}_exact_mode_4k64.txt 2>&1
 for inter in f64 f32t; do
-  timeout -k 10 300 python bench.py --mode stream --batch 32 --chunk 8 --steps 3 --warmup 1 --inter $inter 2>/dev/null | tail -1 >> $O/${TAG}_stream_4k.txt
+  timeout -k 10 300 python bench.py --mode stream --batch 96 --chunk 8 --steps 3 --warmup 1 --inter $inter 2>/dev/null | tail -1 >> $O/${TAG}_stream_4k.txt
 done
 ls -la $O | grep ${TAG}
