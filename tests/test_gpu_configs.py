@@ -224,3 +224,43 @@ def test_bench_stream_mode_two_ranks_rehearsal():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 6 and d["config"]["chunk"] == 4
         assert d["stream_vs_direct_max_lsb"] == 0 and d["value"] > 0 and "configs[4]" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("mode", ["local", "scatter"])
+def test_bench_two_ranks_under_the_drivers_launcher_rehearsal(mode):
+    """The driver's N > 1 launch line, word for word (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`), for the headline mode and for configs[3]'s scatter /
+    gather mode: RANK / LOCAL_RANK / WORLD_SIZE come from the launcher, every rank runs the HIP path on its frames, the elapsed
+    times meet in a MAX reduction and rank 0 alone prints the line, whose `value` counts both ranks' frames.  One-GPU box:
+    UWIE_BENCH_REHEARSAL puts both ranks on GPU 0 with gloo for the reduction and the transfers (RCCL refuses two ranks on one
+    device) -- a rehearsal of the control flow, not a measurement."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UWIE_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    H, W, B, K = 256, 320, 6, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", "1",
+           "--mode", mode, "--height", str(H), "--width", str(W), "--batch", str(B)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == K and d["scaling"] == "weak" and d["value"] > 0
+    frames_per_step = d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / (H * W)
+    assert abs(frames_per_step - 2 * B) < 0.01 * 2 * B, (frames_per_step, d)  # both ranks' frames (scatter: the root's batch)
+    assert "cpu_baseline" not in d  # the CPU oracle is timed by rank 0 at N = 1 only
+    if mode == "local":
+        assert d["roofline"]["kernel"] and d["config"]["parallelism"] == "batch-shard x2"
+    else:
+        assert d["config"]["parallelism"] == "scatter/gather x2" and "gloo rehearsal" in d["config"]["workload"]
